@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- train-step throughput of the hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = nnUNetTrainer.train_step (forward, deep-supervised DC+CE loss, backward, gradient all-reduce, global-norm
+clip, SGD-Nesterov) on the reference's own synthetic benchmark batch
+(nnUNetTrainerBenchmark_5epochs_noDataLoading.py:16-22).  Workload = BASELINE.json configs[1]: PlainConvUNet
+3d_fullres, 6 stages, 31.2 M parameters, 4 modalities, 128^3 patch, fp32, batch 2 per GPU (weak scaling: the global
+batch is 2*N, split by the reference's rule nnUNetTrainer.py:304-349).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "train-step samples/sec on 4-modality 128^3 patches (PlainConvUNet 3d_fullres, fp32)"
+PATCH = (128, 128, 128)
+STRIDES = [[1, 1, 1]] + [[2, 2, 2]] * 5
+IN_CH, NUM_CLASSES, PER_GPU_BATCH = 4, 5, 2
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def dataset_json():
+    return {"channel_names": {str(i): f"mod{i}" for i in range(IN_CH)},
+            "labels": {"background": 0, **{f"c{i}": i for i in range(1, NUM_CLASSES)}}}
+
+
+def time_kernel(fn, iters, torch):
+    """Average duration (ms) of `fn` over `iters` launches, HIP events on the stream the kernels run on."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def dominant_kernel_roofline(torch, dev):
+    """Times the dominant kernel of the step in isolation, live, with HIP events: the 3x3x3 conv forward-type
+    implicit GEMM on the most expensive layer (decoder stage 5 conv 0: 64 -> 32 channels at 128^3, two input
+    pointers = the eliminated torch.cat), batch 2.  ALGORITHMIC flops = 2*27*C_in*C_out*N_out."""
+    from multimodal_mvd_seg_amd import ops
+    from multimodal_mvd_seg_amd._lib import call, i3
+    import ctypes
+    N, C1, C2, K = PER_GPU_BATCH, 32, 32, 32
+    D, H, W = PATCH
+    x1 = ops.empty_cl3d((N, C1, D, H, W), dev).normal_()
+    x2 = ops.empty_cl3d((N, C2, D, H, W), dev).normal_()
+    w = torch.randn(K, C1 + C2, 3, 3, 3, device=dev) * 0.03
+    bias = torch.zeros(K, device=dev)
+    wf, _ = ops.pack_weight(w, False)
+    y = ops.empty_cl3d((N, K, D, H, W), dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def conv():
+        call("mvd_conv3d_fwd", P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, D, H, W, K, i3((3, 3, 3)), i3((1, 1, 1)), s)
+    ms = time_kernel(conv, 3, torch)
+    flops = 2.0 * 27 * (C1 + C2) * K * N * D * H * W
+    conv_tf = flops / (ms * 1e-3) / 1e12
+    alg_bytes = ((C1 + C2) + K) * N * D * H * W * 4.0
+    roof = {"kernel": "conv3d_fwd 64->32 @128^3 (fwd-type implicit GEMM)", "bound": "mfma", "achieved": round(conv_tf, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None, "ms_per_launch": round(ms, 3),
+            "hbm_view": {"algorithmic_GB": round(alg_bytes / 1e9, 3),
+                         "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    # the HBM-bound kernel of the fused block: InstanceNorm+LeakyReLU forward at [2,32,128^3]
+    # algorithmic bytes = 3*C*N*4 (read x for the statistics, read x, write y)
+    g, b = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+
+    def norm():
+        ops.InstanceNormLeakyReLUFn.apply(y, g, b, 1e-5, 0.01)
+    nms = time_kernel(norm, 5, torch)
+    nbytes = 3.0 * K * N * D * H * W * 4
+    ngb = nbytes / (nms * 1e-3) / 1e9
+    roof["instnorm_lrelu_fwd"] = {"bound": "hbm", "achieved": round(ngb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ngb / HBM_PEAK_GBS, 4), "ms_per_launch": round(nms, 3)}
+    return roof
+
+
+def cpu_baseline(torch):
+    """The oracle's torch-CPU train step (same ops, same order as the reference's `-device cpu` path,
+    run_training.py:391-395: all host threads, no autocast) on a bounded sample: ONE step at batch 1 of the same
+    4x128^3 workload."""
+    from oracle import loss_oracle as LO, step_oracle as SO, unet_oracle as UO
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = UO.build_plainconv_unet(IN_CH, NUM_CLASSES, 6, STRIDES, seed=0)
+    batch = SO.synthetic_batch(1, IN_CH, PATCH, STRIDES, num_classes=NUM_CLASSES, seed=1234)
+    loss_fn = LO.build_loss(len(batch["target"]))
+    opt = SO.make_optimizer(net.parameters())
+    t0 = time.perf_counter()
+    SO.train_step(net, loss_fn, opt, batch)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 train step (fwd+loss+bwd+clip+SGD), batch 1, 4x128^3, torch {torch.__version__} CPU fp32, "
+                      f"{dt:.1f} s wall (first step, includes oneDNN primitive creation)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--patch", type=int, nargs=3, default=list(PATCH), help="debug only; the metric is quoted at 128^3")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL over xGMI on ROCm
+
+    from multimodal_mvd_seg_amd import trainer
+    patch = tuple(args.patch)
+    plans = trainer.make_plans(patch, STRIDES, batch_size=PER_GPU_BATCH * world)
+    tr = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, dataset_json(), device=dev)
+    torch.manual_seed(0)
+    tr.initialize()
+    assert tr.batch_size == PER_GPU_BATCH
+    tr.on_train_epoch_start()
+    batch = tr.dummy_batch  # resident in HBM
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(batch)
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = tr.train_step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        samples = PER_GPU_BATCH * world * args.steps
+        out = {"metric": METRIC, "value": round(samples / dt, 4), "unit": "samples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: PlainConvUNet 3d_fullres 6 stages 31.2M params, "
+                                      f"{IN_CH}x{'x'.join(map(str, patch))} patch, {NUM_CLASSES} classes, fp32, "
+                                      "DC+CE deep supervision, SGD-Nesterov+clip",
+                          "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,
+                          "parallelism": f"dp{world}"},
+               "final_loss": float(last["loss"])}
+        if not args.no_roofline:
+            out["roofline"] = dominant_kernel_roofline(torch, dev)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(torch)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

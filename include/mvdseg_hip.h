@@ -1,0 +1,201 @@
+/* mvdseg_hip.h -- C ABI of libmvdseg_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the one
+ * data-parallel hot path of JaronTu/Multimodal_MVD_Seg: the nnU-Net-v2 3d_fullres PlainConvUNet train step
+ * (SURVEY.md section 8).  The reference has NO FFI on this path (it calls torch.nn -> ATen -> cuDNN/MIOpen);
+ * every entry point below cites the reference call site whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller (the PyTorch caching
+ *    allocator on the Python side).  The library never allocates or frees device memory and keeps no pointer
+ *    across calls.  `stream` is a hipStream_t passed as void* (the caller's current stream).
+ *  - return 0 on success, non-zero otherwise; no exception crosses the ABI; mvd_last_error() returns the
+ *    thread-local message of the last failing call.
+ *  - activations are NDHWC fp32 ("channels last 3d"): x[n][d][h][w][c].  Logits, targets and the 1-channel maps
+ *    of the topology losses are planar NCDHW fp32.  Weights cross the boundary in torch layout
+ *    (Conv3d [K][C][kd][kh][kw], ConvTranspose3d [C][K][kd][kh][kw]); mvd_pack_* builds the tap-major shadow
+ *    copies the kernels stream.
+ *  - every reduction is a fixed-order two-stage reduce (no float atomics): results are run-to-run bit-identical.
+ *  - workspaces: caller passes `ws` / `ws_bytes`; mvd_*_workspace_bytes() returns the requirement.
+ */
+#ifndef MVDSEG_HIP_H
+#define MVDSEG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVD_VERSION 100 /* 0.1.0 */
+#define MVD_MAX_TAPS 27
+
+int mvd_version(void);
+const char *mvd_last_error(void);
+/* 1 if the build contains the MFMA implicit-GEMM engine (it always does; kept for host-side asserts) */
+int mvd_has_mfma(void);
+/* force the scalar gather kernels (debug / cross-check): 0 = auto (MFMA when shapes allow), 1 = scalar only */
+int mvd_set_conv_engine(int mode);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight packing.  torch Conv3d weight [K][C][T] (T = kd*kh*kw taps, row-major) ->
+ *   wf[T][C][K]  (forward: reduce over C, produce K)      wb[T][K][C]  (dgrad: reduce over K, produce C)
+ * `transposed` != 0: source is a ConvTranspose3d weight [C][K][T] (same two outputs).
+ * Replaces nothing in the reference (torch keeps one layout); it is the price of the tap-major layout. */
+int mvd_pack_weight(const float *w, float *wf, float *wb, int K, int C, int T, int transposed, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Conv3d, kernel k[a] in {1,3}, padding (k-1)/2, stride s[a] in {1,2}, dilation 1 (K1/K5/K6 of SURVEY 2.4).
+ * Replaces torch.nn.Conv3d inside every ConvDropoutNormReLU (get_network_from_plans.py:39-45,
+ * UNetDecoder.py:61-65) and the decoder's torch.cat((x, skip), 1) (UNetDecoder.py:107): the input is the channel
+ * concatenation of x1 [N,D,H,W,C1] and x2 [N,D,H,W,C2] (x2 may be NULL with C2 = 0).
+ *   y[n,o,k] = bias[k] + sum_t sum_c x[n, o*s + t - pad, c] * wf[t][c][k],   y: [N,Do,Ho,Wo,K]
+ * Do = (D + 2*pad - k)/s + 1. */
+int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *bias, float *y,
+                   int N, int D, int H, int W, int K, const int ksize[3], const int stride[3], void *stream);
+/* dgrad: dx = conv_transpose(dy, w); written as dx1 [.,C1] and dx2 [.,C2] (channel split of the concat). */
+int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float *dx2, int C2, int N, int D, int H,
+                     int W, int K, const int ksize[3], const int stride[3], void *stream);
+/* wgrad: dw in TORCH layout [K][C1+C2][T], dbias [K] (may be NULL).  Fixed-order split reduction through `ws`. */
+size_t mvd_conv3d_wgrad_workspace_bytes(int C, int K, int T, int N, int Do, int Ho, int Wo);
+int mvd_conv3d_wgrad(const float *x1, int C1, const float *x2, int C2, const float *dy, float *dw, float *dbias,
+                     int N, int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws,
+                     size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ConvTranspose3d with kernel == stride (non-overlapping; K2).  Replaces the decoder's transpconvs
+ * (UNetDecoder.py:56-59,106).  x: [N,D,H,W,C] -> y: [N,D*s0,H*s1,W*s2,K];  wf[T][C][K], T = s0*s1*s2.
+ *   y[n, q*s + p, k] = bias[k] + sum_c x[n,q,c] * w[c][k][p] */
+int mvd_convT3d_fwd(const float *x, const float *wf, const float *bias, float *y, int N, int D, int H, int W, int C,
+                    int K, const int stride[3], void *stream);
+int mvd_convT3d_dgrad(const float *dy, const float *wb, float *dx, int N, int D, int H, int W, int C, int K,
+                      const int stride[3], void *stream);
+size_t mvd_convT3d_wgrad_workspace_bytes(int C, int K, int T, int N, int D, int H, int W);
+/* dw in TORCH layout [C][K][T], dbias [K] */
+int mvd_convT3d_wgrad(const float *x, const float *dy, float *dw, float *dbias, int N, int D, int H, int W, int C,
+                      int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * InstanceNorm3d(eps, affine) + LeakyReLU(slope), fused (K3/K4).  Replaces nn.InstanceNorm3d + nn.LeakyReLU of
+ * every ConvDropoutNormReLU (get_network_from_plans.py:41-44).  x,y: [N,V,C] NDHWC with V = D*H*W.
+ * Biased variance over V, no running stats.  mean/rstd [N][C] are outputs (saved for backward).
+ * ws: 2*N*nblk*C doubles (nblk from mvd_instnorm_nblk). */
+int mvd_instnorm_nblk(int N, long V, int C);
+size_t mvd_instnorm_workspace_bytes(int N, long V, int C);
+int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                           float *rstd, int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes,
+                           void *stream);
+/* dx [N,V,C]; dgamma/dbeta [C] (overwritten).  Recomputes z = xhat*gamma+beta from x for the LeakyReLU mask. */
+int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, const float *beta,
+                           const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta, int N,
+                           long V, int C, float slope, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 1x1x1 segmentation head (K5): x NDHWC [N,V,C] -> logits planar [N,K,V].  Replaces decoder.seg_layers[s]
+ * (UNetDecoder.py:70,110).  w: torch layout [K][C], bias [K]. */
+int mvd_seghead_fwd(const float *x, const float *w, const float *bias, float *logits, int N, long V, int C, int K,
+                    void *stream);
+/* dx [N,V,C] (overwritten, or accumulated into when accumulate != 0); dw [K][C], dbias [K] */
+size_t mvd_seghead_bwd_workspace_bytes(int N, long V, int C, int K);
+int mvd_seghead_bwd(const float *x, const float *w, const float *dlogits, float *dx, float *dw, float *dbias, int N,
+                    long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused softmax + cross-entropy + soft-Dice statistics (K7).  Replaces DC_and_CE_loss
+ * (nnUNetTrainer.py:359-361: RobustCrossEntropyLoss + MemoryEfficientSoftDiceLoss{smooth 1e-5, do_bg False}).
+ * logits planar [N,K,V]; target float labels [N,V] (robust_ce_loss.py:12-16 casts float->long).
+ * fwd: stats[N][3K+1]: per sample (sum p*y, sum p, sum y) for k = 0..K-1, then the sample's sum_vox -log p_target
+ * (fp64 accumulation, fixed order, rounded once to fp32).  This is also the tensor that is all-gathered for
+ * DDP batch-dice (ddp_allgather.py:25-48, collective C2).
+ * mvd_dcce_finalize does the scalar composition (dc = (2I+s)/clip(G+P+s,1e-8); mean over (n, k>=kstart);
+ * batch_dice sums over n first) and emits the per-(n,k) Dice gradient coefficients used by bwd.  The Dice part may
+ * be evaluated on a different sample set (`dstats`, Nd samples: the all-gathered stats) than the CE part. */
+size_t mvd_dcce_workspace_bytes(int N, long V, int K);
+int mvd_dcce_fwd(const float *logits, const float *target, float *stats /*[N][3K+1]*/, int N, long V, int K, void *ws,
+                 size_t ws_bytes, void *stream);
+/* loss[0] = w_ce*CE + w_dice*(-mean dc); loss[1] = CE; loss[2] = -mean dc;
+ * coef[Nd][K][2] = w_dice * (dLdice/dI, dLdice/dP) (zero for k < kstart). */
+int mvd_dcce_finalize(const float *stats, int N, const float *dstats, int Nd, float *loss, float *coef, long V, int K,
+                      int batch_dice, int do_bg, float smooth, float w_ce, float w_dice, void *stream);
+/* dlogits[n,k,v] = g * ( w_ce/(N*V) * (p_k - y_k) + p_k * (q_k - sum_j p_j q_j) ),  q_k = coefI[n,k]*y_k + coefP[n,k],
+ * g = gscale_host * (gscale_dev ? gscale_dev[0] : 1) */
+int mvd_dcce_bwd(const float *logits, const float *target, const float *coef /*[N][K][2]*/, const float *gscale_dev,
+                 float gscale_host, float *dlogits, int N, long V, int K, float w_ce, void *stream);
+/* p_sel[n,v] = softmax(logits[n,:,v])[sel] (MVDTrainer.py:907 takes channel 2 of the prediction for the topology
+ * term; the build feeds the probability to soft-clDice).  bwd: dlogits[n,k,v] = g[n,v] * p_sel * ((k==sel) - p_k). */
+int mvd_softmax_select_fwd(const float *logits, float *p_sel, int N, long V, int K, int sel, void *stream);
+int mvd_softmax_select_bwd(const float *logits, const float *g, float *dlogits, int N, long V, int K, int sel,
+                           void *stream);
+/* mask[i] = (labels[i] == value) ? 1.f : 0.f  (one-hot channel `value` of the target, MVDTrainer.py:904-908) */
+int mvd_label_mask(const float *labels, float *mask, long n, float value, void *stream);
+/* validation: argmax -> one-hot -> tp/fp/fn per class over (n, v) (nnUNetTrainer.py:973-990).  counts[K][3] i64 */
+int mvd_argmax_counts(const float *logits, const float *target, long long *counts, int N, long V, int K,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * KL distillation (K8).  Replaces distill_kl / l2_loss(channel_wise=True) (other_loss.py:51-64, :67-76):
+ *   loss = T^2/(N*Ceff*V) * sum p_t * (log p_t - log_softmax(y_s/T + eps_s)),  p_t = softmax(y_t/T) over channels.
+ * Element (n,c,v) lives at n*sn + c*sc + v*sv (planar: sc = V, sv = 1; NDHWC: sc = 1, sv = C).
+ * pad_zero_channel != 0 implements the C == 1 branch (:55-57): a zero logit channel is appended (Ceff = 2).
+ * out[0] = loss.  bwd writes g_s, g_t (either may be NULL) = gscale[0] * dloss/dy. */
+size_t mvd_kl_workspace_bytes(int N, long V);
+int mvd_kl_fwd(const float *ys, const float *yt, float *out, int N, int C, long V, long sn, long sc, long sv,
+               float T, float eps_s, int pad_zero_channel, void *ws, size_t ws_bytes, void *stream);
+int mvd_kl_bwd(const float *ys, const float *yt, const float *gscale_dev, float gscale_host, float *gs, float *gt,
+               int N, int C, long V, long sn, long sc, long sv, float T, float eps_s, int pad_zero_channel,
+               void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Soft skeleton primitives (K9).  Replace soft_erode / soft_dilate of soft_skeleton.py:6-22 on planar volumes
+ * [NC, D, H, W].  Bit-exact vs torch CPU (min/max only).  bwd reproduces autograd's routing: max_pool3d sends the
+ * gradient to the FIRST maximum in scan order; torch.min(a,b) splits ties 1/2-1/2 (so the three axis pools of
+ * erode get 1/4,1/4,1/2 on a triple tie). */
+/* `code` (optional in fwd, required by bwd): per-voxel routing record written by fwd (uint16 for erode: arg-min
+ * position per axis + tie pattern; uint8 for dilate: arg-max position 0..26 in the 3x3x3 window). */
+int mvd_soft_erode_fwd(const float *x, float *y, uint16_t *code, int NC, int D, int H, int W, void *stream);
+int mvd_soft_erode_bwd(const uint16_t *code, const float *dy, float *dx, int NC, int D, int H, int W, void *stream);
+int mvd_soft_dilate_fwd(const float *x, float *y, uint8_t *code, int NC, int D, int H, int W, void *stream);
+int mvd_soft_dilate_bwd(const uint8_t *code, const float *dy, float *dx, int NC, int D, int H, int W, void *stream);
+/* skeleton update (soft_skeleton.py:31,35-36): delta = relu(img - opened); init: skel = delta;
+ * else skel_out = skel + relu(delta - skel*delta) (no FMA contraction).  n = element count. */
+int mvd_skel_update_fwd(const float *img, const float *opened, const float *skel_in, float *skel_out, long n,
+                        int init, void *stream);
+/* grads: d_img, d_opened (= -d_img masked), d_skel_in (NULL when init) from d_skel_out */
+int mvd_skel_update_bwd(const float *img, const float *opened, const float *skel_in, const float *d_skel_out,
+                        float *d_img, float *d_opened, float *d_skel_in, long n, int init, void *stream);
+/* sums for soft-clDice: out[0] = sum a*b, out[1] = sum a  (fixed-order) */
+int mvd_dot_sum(const float *a, const float *b, float *out, long n, void *ws, size_t ws_bytes, void *stream);
+size_t mvd_dot_sum_workspace_bytes(long n);
+
+/* soft-clDice scalar composition (clDice_metric.py:7-36 formula on soft skeletons):
+ * sums = (sum skel_p*tgt, sum skel_p, sum skel_t*pred, sum skel_t); tprec = (s0+smooth)/(s1+smooth),
+ * tsens = (s2+smooth)/(s3+smooth); out[0] = 1 - 2*tprec*tsens/(tprec+tsens); out[1..4] = d out[0] / d sums[0..3]. */
+int mvd_cldice_combine(const float *sums, float *out, float smooth, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Connected components on a voxel grid (K12; integer, bit-exact).  Replaces the H0 / connected-component step the
+ * reference runs on the CPU through the vendored TopologyLayer C++ (hom.cpp:51-69 restricted to vertices+edges
+ * == union-find).  mask: uint8 [D,H,W]; labels int32 [D,H,W]: 0 = background, else 1 + smallest linear index of
+ * the component (canonical).  conn in {6, 14, 26}.  count[0] = number of components. */
+int mvd_cc_label(const uint8_t *mask, int32_t *labels, int32_t *count, int D, int H, int W, int conn, void *stream);
+/* mask[v] = (f[v] > thr) (or >= when ge != 0) */
+int mvd_threshold_mask(const float *f, uint8_t *mask, long n, float thr, int ge, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SGD(momentum, nesterov, weight decay) with global-norm clipping (K10).  Replaces
+ * torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step (nnUNetTrainer.py:473-477, :918-924) on flat
+ * parameter / gradient / momentum buffers of n floats.
+ *   sumsq: out[0] = sum g^2 (fixed-order).  step: g *= min(1, max_norm/(sqrt(sumsq)+1e-6)) (clip_scale read from
+ *   device memory: no host sync); g += wd*p; buf = first ? g : mom*buf + g; g = g + mom*buf (nesterov); p -= lr*g */
+size_t mvd_sumsq_workspace_bytes(long n);
+int mvd_grad_sumsq(const float *g, float *out, long n, void *ws, size_t ws_bytes, void *stream);
+int mvd_sgd_nesterov_step(float *p, const float *g, float *buf, const float *sumsq, long n, float lr, float momentum,
+                          float weight_decay, float max_norm, int first_step, void *stream);
+
+/* misc elementwise helpers used by the host glue (all fixed-order / exact) */
+int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *stream);
+int mvd_ndhwc_to_nchw(const float *src, float *dst, int N, int C, long V, void *stream);
+int mvd_axpy(float *y, const float *x, float a, long n, void *stream); /* y += a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVDSEG_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libmvdseg_hip.so (the C ABI declared in include/mvdseg_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised
+(the reference treats RuntimeError as "OOM-like", nnUNetTrainer.py:1187, nnUNetTrainerBenchmark_5epochs.py:28).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvdseg_hip.so")
+
+_P = c_void_p
+_I3 = ctypes.c_int * 3
+
+# name -> (restype, argtypes); must list every symbol of include/mvdseg_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "mvd_version": (c_int, []),
+    "mvd_last_error": (ctypes.c_char_p, []),
+    "mvd_has_mfma": (c_int, []),
+    "mvd_set_conv_engine": (c_int, [c_int]),
+    "mvd_pack_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mvd_conv3d_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P]),
+    "mvd_conv3d_dgrad": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P]),
+    "mvd_conv3d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mvd_conv3d_wgrad": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
+                                 c_size_t, _P]),
+    "mvd_convT3d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P]),
+    "mvd_convT3d_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P]),
+    "mvd_convT3d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mvd_convT3d_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
+    "mvd_instnorm_nblk": (c_int, [c_int, c_long, c_int]),
+    "mvd_instnorm_workspace_bytes": (c_size_t, [c_int, c_long, c_int]),
+    "mvd_instnorm_lrelu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, c_float, _P, c_size_t, _P]),
+    "mvd_instnorm_lrelu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, _P, c_size_t,
+                                       _P]),
+    "mvd_seghead_fwd": (c_int, [_P, _P, _P, _P, c_int, c_long, c_int, c_int, _P]),
+    "mvd_seghead_bwd_workspace_bytes": (c_size_t, [c_int, c_long, c_int, c_int]),
+    "mvd_seghead_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "mvd_dcce_workspace_bytes": (c_size_t, [c_int, c_long, c_int]),
+    "mvd_dcce_fwd": (c_int, [_P, _P, _P, c_int, c_long, c_int, _P, c_size_t, _P]),
+    "mvd_dcce_finalize": (c_int, [_P, c_int, _P, c_int, _P, _P, c_long, c_int, c_int, c_int, c_float, c_float, c_float,
+                                  _P]),
+    "mvd_dcce_bwd": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, c_long, c_int, c_float, _P]),
+    "mvd_argmax_counts": (c_int, [_P, _P, _P, c_int, c_long, c_int, _P]),
+    "mvd_softmax_select_fwd": (c_int, [_P, _P, c_int, c_long, c_int, c_int, _P]),
+    "mvd_softmax_select_bwd": (c_int, [_P, _P, _P, c_int, c_long, c_int, c_int, _P]),
+    "mvd_label_mask": (c_int, [_P, _P, c_long, c_float, _P]),
+    "mvd_cldice_combine": (c_int, [_P, _P, c_float, _P]),
+    "mvd_kl_workspace_bytes": (c_size_t, [c_int, c_long]),
+    "mvd_kl_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_float, c_int, _P,
+                           c_size_t, _P]),
+    "mvd_kl_bwd": (c_int, [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_float,
+                           c_int, _P]),
+    "mvd_soft_erode_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mvd_soft_erode_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mvd_soft_dilate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mvd_soft_dilate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mvd_skel_update_fwd": (c_int, [_P, _P, _P, _P, c_long, c_int, _P]),
+    "mvd_skel_update_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_long, c_int, _P]),
+    "mvd_dot_sum": (c_int, [_P, _P, _P, c_long, _P, c_size_t, _P]),
+    "mvd_dot_sum_workspace_bytes": (c_size_t, [c_long]),
+    "mvd_cc_label": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mvd_threshold_mask": (c_int, [_P, _P, c_long, c_float, c_int, _P]),
+    "mvd_sumsq_workspace_bytes": (c_size_t, [c_long]),
+    "mvd_grad_sumsq": (c_int, [_P, _P, c_long, _P, c_size_t, _P]),
+    "mvd_sgd_nesterov_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, _P]),
+    "mvd_nchw_to_ndhwc": (c_int, [_P, _P, c_int, c_int, c_long, _P]),
+    "mvd_ndhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_long, _P]),
+    "mvd_axpy": (c_int, [_P, _P, c_float, c_long, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (built by __graft_entry__.build() / csrc/Makefile).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C multimodal_mvd_seg_amd/csrc`).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def i3(v):
+    return _I3(int(v[0]), int(v[1]), int(v[2]))
+
+
+def call(name, *args):
+    """Call an `int`-returning entry point; raise RuntimeError(mvd_last_error()) on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (status {rc}): {lib.mvd_last_error().decode()}")
+
+
+def query(name, *args):
+    """Call a value-returning entry point (workspace sizes etc.)."""
+    return getattr(load(), name)(*args)

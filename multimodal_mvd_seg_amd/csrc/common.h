@@ -1,0 +1,72 @@
+// Internal helpers shared by the kernel translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mvdseg_hip.h"
+
+namespace mvd {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+
+#define MVD_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            mvd::set_error(__VA_ARGS__);  \
+            return 2;                     \
+        }                                 \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// 64-lane wavefront reductions (CDNA wave = 64)
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Block-wide sum of NV doubles per thread; result valid in thread 0.  blockDim.x multiple of 64, <= 1024.
+template <int NV>
+__device__ inline void block_sum(double (&v)[NV], double *smem /* >= NV*16 doubles */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) smem[i * 16 + wid] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            double s = 0;
+            for (int w = 0; w < nw; w++) s += smem[i * 16 + w];
+            v[i] = s;
+        }
+    }
+}
+
+// generic fixed-order second stage: out[j] = sum_b partial[b*stride + offset + j]  (double -> float), j < nv
+int reduce_partials(const double *partials, float *out, int nblk, int nv, hipStream_t s, int stride = 0, int offset = 0);
+
+}  // namespace mvd

@@ -1,0 +1,130 @@
+// Error plumbing, version, layout helpers and the shared fixed-order second-stage reducer.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace mvd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__global__ void k_reduce_partials(const double *__restrict__ partials, float *__restrict__ out, int nblk, int stride,
+                                  int offset) {
+    // one wave per output value, lanes stride over blocks, fixed shuffle tree -> deterministic
+    int j = blockIdx.x;
+    double s = 0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partials[(size_t)b * stride + offset + j];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[j] = (float)s;
+}
+
+int reduce_partials(const double *partials, float *out, int nblk, int nv, hipStream_t s, int stride, int offset) {
+    if (stride <= 0) stride = nv;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nv), dim3(64), 0, s, partials, out, nblk, stride, offset);
+    return check_launch("reduce_partials");
+}
+
+// ---------------------------------------------------------------- layout transposes  [N][C][V] <-> [N][V][C]
+// 32 voxels x C tile through LDS so both sides are coalesced.
+__global__ void k_nchw_to_ndhwc(const float *__restrict__ src, float *__restrict__ dst, int C, long V) {
+    __shared__ float tile[32][33];
+    long v0 = (long)blockIdx.x * 32;
+    int c0 = blockIdx.y * 32;
+    int n = blockIdx.z;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r;
+        long v = v0 + tx;
+        tile[r][tx] = (c < C && v < V) ? src[((size_t)n * C + c) * V + v] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        long v = v0 + r;
+        int c = c0 + tx;
+        if (c < C && v < V) dst[((size_t)n * V + v) * C + c] = tile[tx][r];
+    }
+}
+__global__ void k_ndhwc_to_nchw(const float *__restrict__ src, float *__restrict__ dst, int C, long V) {
+    __shared__ float tile[32][33];
+    long v0 = (long)blockIdx.x * 32;
+    int c0 = blockIdx.y * 32;
+    int n = blockIdx.z;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        long v = v0 + r;
+        int c = c0 + tx;
+        tile[r][tx] = (c < C && v < V) ? src[((size_t)n * V + v) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r;
+        long v = v0 + tx;
+        if (c < C && v < V) dst[((size_t)n * C + c) * V + v] = tile[tx][r];
+    }
+}
+
+__global__ void k_axpy(float *__restrict__ y, const float *__restrict__ x, float a, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = y[i] + a * x[i];
+}
+
+// torch [K][C][T] (or transposed-conv [C][K][T]) -> wf[T][C][K], wb[T][K][C]
+__global__ void k_pack_weight(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wb, int K,
+                              int C, int T, int transposed) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)K * C * T;
+    if (i >= total) return;
+    // i indexes wf: [t][c][k]
+    int k = i % K;
+    int c = (i / K) % C;
+    int t = i / ((long)K * C);
+    float v = transposed ? w[((size_t)c * K + k) * T + t] : w[((size_t)k * C + c) * T + t];
+    if (wf) wf[i] = v;
+    if (wb) wb[((size_t)t * K + k) * C + c] = v;
+}
+
+}  // namespace mvd
+
+using namespace mvd;
+
+extern "C" {
+
+int mvd_version(void) { return MVD_VERSION; }
+const char *mvd_last_error(void) { return g_err; }
+int mvd_has_mfma(void) { return 1; }
+
+int mvd_pack_weight(const float *w, float *wf, float *wb, int K, int C, int T, int transposed, void *stream) {
+    MVD_REQUIRE(w && (wf || wb) && K > 0 && C > 0 && T > 0 && T <= MVD_MAX_TAPS, "pack_weight: bad arguments");
+    long total = (long)K * C * T;
+    hipLaunchKernelGGL(k_pack_weight, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, wf, wb, K, C, T,
+                       transposed);
+    return check_launch("pack_weight");
+}
+
+int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *stream) {
+    MVD_REQUIRE(src && dst && N > 0 && C > 0 && V > 0 && N <= 65535, "nchw_to_ndhwc: bad arguments");
+    dim3 g(cdiv(V, 32), cdiv(C, 32), N);
+    hipLaunchKernelGGL(k_nchw_to_ndhwc, g, dim3(256), 0, as_stream(stream), src, dst, C, V);
+    return check_launch("nchw_to_ndhwc");
+}
+int mvd_ndhwc_to_nchw(const float *src, float *dst, int N, int C, long V, void *stream) {
+    MVD_REQUIRE(src && dst && N > 0 && C > 0 && V > 0 && N <= 65535, "ndhwc_to_nchw: bad arguments");
+    dim3 g(cdiv(V, 32), cdiv(C, 32), N);
+    hipLaunchKernelGGL(k_ndhwc_to_nchw, g, dim3(256), 0, as_stream(stream), src, dst, C, V);
+    return check_launch("ndhwc_to_nchw");
+}
+int mvd_axpy(float *y, const float *x, float a, long n, void *stream) {
+    MVD_REQUIRE(y && x && n > 0, "axpy: bad arguments");
+    long blocks = cdiv(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_axpy, dim3(blocks), dim3(256), 0, as_stream(stream), y, x, a, n);
+    return check_launch("axpy");
+}
+}

@@ -1,0 +1,485 @@
+// Conv3d / ConvTranspose3d entry points: geometry set-up, engine dispatch (MFMA implicit GEMM when the shape allows,
+// scalar gather kernels otherwise) and the scalar engines themselves.
+#include "common.h"
+#include "conv_geom.h"
+
+namespace mvd {
+
+static int g_engine_mode = 0;  // 0 auto, 1 scalar only
+
+// =============================================================================================== scalar forward-type
+// one thread per (n, o, k); k fastest so weight reads and output writes are coalesced and A is a wave broadcast
+__global__ void k_fwd_scalar(FwdGeom g, const float *__restrict__ a1, const float *__restrict__ a2,
+                             const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ y1,
+                             float *__restrict__ y2) {
+    const int K = g.K1 + g.K2, C = g.C1 + g.C2;
+    const long total = (long)g.N * g.Do * g.Ho * g.Wo * K;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int k = (int)(idx % K);
+        long r = idx / K;
+        int ow = (int)(r % g.Wo);
+        r /= g.Wo;
+        int oh = (int)(r % g.Ho);
+        r /= g.Ho;
+        int od = (int)(r % g.Do);
+        int n = (int)(r / g.Do);
+        float acc = bias ? bias[k] : 0.f;
+        for (int t = 0; t < g.ntaps; t++) {
+            int id = od * g.sa[0] + g.off[t][0], ih = oh * g.sa[1] + g.off[t][1], iw = ow * g.sa[2] + g.off[t][2];
+            if (id < 0 || id >= g.Di || ih < 0 || ih >= g.Hi || iw < 0 || iw >= g.Wi) continue;
+            size_t vox = (((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw;
+            const float *wt = w + (size_t)g.wt[t] * C * K + k;
+            const float *p1 = a1 + vox * g.C1;
+            for (int c = 0; c < g.C1; c++) acc += p1[c] * wt[(size_t)c * K];
+            if (g.C2) {
+                const float *p2 = a2 + vox * g.C2;
+                const float *wt2 = wt + (size_t)g.C1 * K;
+                for (int c = 0; c < g.C2; c++) acc += p2[c] * wt2[(size_t)c * K];
+            }
+        }
+        size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                    (ow * g.so[2] + g.oo[2]);
+        if (k < g.K1)
+            y1[ov * g.K1 + k] = acc;
+        else
+            y2[ov * g.K2 + (k - g.K1)] = acc;
+    }
+}
+
+int fwd_scalar(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
+               float *y2, hipStream_t s) {
+    long total = (long)g.N * g.Do * g.Ho * g.Wo * (g.K1 + g.K2);
+    if (total <= 0) return 0;
+    long blocks = cdiv(total, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_fwd_scalar, dim3(blocks), dim3(256), 0, s, g, a1, a2, w, bias, y1, y2);
+    return check_launch("conv fwd (scalar)");
+}
+
+// =============================================================================================== scalar wgrad-type
+// grid (ceil(ntaps*C*K/256), nsplit): each thread owns one (t,c,k) and a slice of the voxels; fp64 partials,
+// fixed-order second stage.
+__global__ void k_wgrad_scalar(WgradGeom g, const float *__restrict__ a1, const float *__restrict__ a2,
+                               const float *__restrict__ b, double *__restrict__ partial, long chunk) {
+    const int C = g.C1 + g.C2, K = g.K;
+    const long per = (long)g.ntaps * C * K;
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= per) return;
+    const int k = (int)(j % K);
+    const int c = (int)((j / K) % C);
+    const int t = (int)(j / ((long)K * C));
+    const long total = (long)g.N * g.Do * g.Ho * g.Wo;
+    const long v0 = (long)blockIdx.y * chunk;
+    long v1 = v0 + chunk;
+    if (v1 > total) v1 = total;
+    double acc = 0.0;
+    for (long v = v0; v < v1; v++) {
+        long r = v;
+        int ow = (int)(r % g.Wo);
+        r /= g.Wo;
+        int oh = (int)(r % g.Ho);
+        r /= g.Ho;
+        int od = (int)(r % g.Do);
+        int n = (int)(r / g.Do);
+        int id = od * g.sa[0] + g.off[t][0], ih = oh * g.sa[1] + g.off[t][1], iw = ow * g.sa[2] + g.off[t][2];
+        if (id < 0 || id >= g.Di || ih < 0 || ih >= g.Hi || iw < 0 || iw >= g.Wi) continue;
+        int bd = od * g.sb[0] + g.ob[t][0], bh = oh * g.sb[1] + g.ob[t][1], bw = ow * g.sb[2] + g.ob[t][2];
+        if (bd < 0 || bd >= g.Db || bh < 0 || bh >= g.Hb || bw < 0 || bw >= g.Wb) continue;
+        size_t va = (((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw;
+        size_t vb = (((size_t)n * g.Db + bd) * g.Hb + bh) * g.Wb + bw;
+        float av = c < g.C1 ? a1[va * g.C1 + c] : a2[va * g.C2 + (c - g.C1)];
+        acc += (double)(av * b[vb * K + k]);
+    }
+    partial[(size_t)blockIdx.y * per + j] = acc;
+}
+
+// dw[torch layout] = sum_split partial[split][t][c][k]
+__global__ void k_wgrad_reduce_d(WgradGeom g, const double *__restrict__ partial, float *__restrict__ dw, int nsplit) {
+    const int C = g.C1 + g.C2, K = g.K;
+    const long per = (long)g.ntaps * C * K;
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= per) return;
+    double s = 0;
+    for (int b = 0; b < nsplit; b++) s += partial[(size_t)b * per + j];
+    const int k = (int)(j % K);
+    const int c = (int)((j / K) % C);
+    const int t = g.wt[(int)(j / ((long)K * C))];
+    size_t o = g.transposed_out ? ((size_t)c * K + k) * g.T + t : ((size_t)k * C + c) * g.T + t;
+    dw[o] = (float)s;
+}
+
+static int wgrad_scalar_split(const WgradGeom &g, long *chunk) {
+    long total = (long)g.N * g.Do * g.Ho * g.Wo;
+    long per = (long)g.ntaps * (g.C1 + g.C2) * g.K;
+    long nsplit = cdiv(total, 512);
+    long cap = (64L << 20) / (per * 8);  // keep the partial buffer <= 64 MiB
+    if (cap < 1) cap = 1;
+    if (nsplit > cap) nsplit = cap;
+    if (nsplit > 256) nsplit = 256;
+    if (nsplit < 1) nsplit = 1;
+    *chunk = cdiv(total, nsplit);
+    return (int)cdiv(total, *chunk);
+}
+
+size_t wgrad_scalar_ws(const WgradGeom &g) {
+    long chunk;
+    int ns = wgrad_scalar_split(g, &chunk);
+    return (size_t)ns * g.ntaps * (g.C1 + g.C2) * g.K * sizeof(double) + 256;
+}
+
+int wgrad_scalar(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws,
+                 size_t ws_bytes, hipStream_t s) {
+    long chunk;
+    int ns = wgrad_scalar_split(g, &chunk);
+    MVD_REQUIRE(ws_bytes >= wgrad_scalar_ws(g), "conv wgrad (scalar): workspace too small");
+    long per = (long)g.ntaps * (g.C1 + g.C2) * g.K;
+    double *partial = reinterpret_cast<double *>(ws);
+    hipLaunchKernelGGL(k_wgrad_scalar, dim3(cdiv(per, 256), ns), dim3(256), 0, s, g, a1, a2, b, partial, chunk);
+    if (check_launch("conv wgrad (scalar)")) return 1;
+    hipLaunchKernelGGL(k_wgrad_reduce_d, dim3(cdiv(per, 256)), dim3(256), 0, s, g, partial, dw, ns);
+    return check_launch("conv wgrad reduce");
+}
+
+// =============================================================================================== bias gradient
+// dbias[k] = sum over rows of dy[rows][K]
+__global__ void k_colsum(const float *__restrict__ x, double *__restrict__ partial, long rows, int K, long chunk) {
+    __shared__ double sm[256];
+    const int t = threadIdx.x;
+    const long r0 = (long)blockIdx.x * chunk;
+    long r1 = r0 + chunk;
+    if (r1 > rows) r1 = rows;
+    if (K <= 256) {
+        const int R = 256 / K;  // rows in flight; lanes walk a row contiguously
+        const int k = t % K, r = t / K;
+        double acc = 0;
+        if (r < R)
+            for (long i = r0 + r; i < r1; i += R) acc += (double)x[(size_t)i * K + k];
+        sm[t] = (r < R) ? acc : 0.0;
+        __syncthreads();
+        if (t < K) {
+            double s = 0;
+            for (int rr = 0; rr < R; rr++) s += sm[rr * K + t];
+            partial[(size_t)blockIdx.x * K + t] = s;
+        }
+    } else {
+        for (int kk = t; kk < K; kk += 256) {
+            double acc = 0;
+            for (long i = r0; i < r1; i++) acc += (double)x[(size_t)i * K + kk];
+            partial[(size_t)blockIdx.x * K + kk] = acc;
+        }
+    }
+}
+
+static int colsum_blocks(long rows, long *chunk) {
+    long nb = rows / 1024;
+    if (nb < 1) nb = 1;
+    if (nb > 512) nb = 512;
+    *chunk = cdiv(rows, nb);
+    return (int)cdiv(rows, *chunk);
+}
+static size_t colsum_ws(long rows, int K) {
+    long chunk;
+    return (size_t)colsum_blocks(rows, &chunk) * K * sizeof(double) + 256;
+}
+static int colsum(const float *x, float *out, long rows, int K, void *ws, hipStream_t s) {
+    long chunk;
+    int nb = colsum_blocks(rows, &chunk);
+    double *partial = reinterpret_cast<double *>(ws);
+    hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, x, partial, rows, K, chunk);
+    if (check_launch("bias grad")) return 1;
+    return reduce_partials(partial, out, nb, K, s);
+}
+
+// =============================================================================================== geometry builders
+static inline int out_dim(int in, int k, int s) { return (in + 2 * ((k - 1) / 2) - k) / s + 1; }
+
+static int check_ks(const int ks[3], const int st[3], const char *who) {
+    for (int a = 0; a < 3; a++) {
+        if (!(ks[a] == 1 || ks[a] == 3)) {
+            set_error("%s: kernel size must be 1 or 3 per axis (got %d)", who, ks[a]);
+            return 1;
+        }
+        if (!(st[a] == 1 || st[a] == 2)) {
+            set_error("%s: stride must be 1 or 2 per axis (got %d)", who, st[a]);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+static void conv_fwd_geom(FwdGeom &g, int N, int D, int H, int W, int C1, int C2, int K, const int ks[3],
+                          const int st[3]) {
+    memset(&g, 0, sizeof(g));
+    g.N = N;
+    g.Di = D; g.Hi = H; g.Wi = W;
+    g.Do = out_dim(D, ks[0], st[0]); g.Ho = out_dim(H, ks[1], st[1]); g.Wo = out_dim(W, ks[2], st[2]);
+    g.Dy = g.Do; g.Hy = g.Ho; g.Wy = g.Wo;
+    g.C1 = C1; g.C2 = C2; g.K1 = K; g.K2 = 0;
+    int t = 0;
+    for (int a = 0; a < ks[0]; a++)
+        for (int b = 0; b < ks[1]; b++)
+            for (int c = 0; c < ks[2]; c++) {
+                g.off[t][0] = a - (ks[0] - 1) / 2;
+                g.off[t][1] = b - (ks[1] - 1) / 2;
+                g.off[t][2] = c - (ks[2] - 1) / 2;
+                g.wt[t] = t;
+                t++;
+            }
+    g.ntaps = t;
+    for (int a = 0; a < 3; a++) {
+        g.sa[a] = st[a];
+        g.so[a] = 1;
+        g.oo[a] = 0;
+    }
+}
+
+static int run_fwd(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
+                   float *y2, hipStream_t s) {
+    if (g_engine_mode == 0) {
+        int r = fwd_mfma(g, a1, a2, w, bias, y1, y2, s);
+        if (r >= 0) return r;
+    }
+    return fwd_scalar(g, a1, a2, w, bias, y1, y2, s);
+}
+
+static int run_wgrad(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws,
+                     size_t ws_bytes, hipStream_t s) {
+    if (g_engine_mode == 0) {
+        int r = wgrad_mfma(g, a1, a2, b, dw, ws, ws_bytes, s);
+        if (r >= 0) return r;
+    }
+    return wgrad_scalar(g, a1, a2, b, dw, ws, ws_bytes, s);
+}
+
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+}  // namespace mvd
+
+using namespace mvd;
+
+extern "C" {
+
+int mvd_set_conv_engine(int mode) {
+    g_engine_mode = mode ? 1 : 0;
+    return 0;
+}
+
+int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *bias, float *y, int N,
+                   int D, int H, int W, int K, const int ksize[3], const int stride[3], void *stream) {
+    MVD_REQUIRE(x1 && wf && y && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_fwd: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_fwd: bad shape");
+    if (check_ks(ksize, stride, "conv3d_fwd")) return 2;
+    FwdGeom g;
+    conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    return run_fwd(g, x1, x2, wf, bias, y, nullptr, as_stream(stream));
+}
+
+int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float *dx2, int C2, int N, int D, int H, int W,
+                     int K, const int ksize[3], const int stride[3], void *stream) {
+    MVD_REQUIRE(dy && wb && dx1 && C1 > 0 && C2 >= 0 && (C2 == 0 || dx2), "conv3d_dgrad: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_dgrad: bad shape");
+    if (check_ks(ksize, stride, "conv3d_dgrad")) return 2;
+    const int dims[3] = {D, H, W};
+    int od[3], pad[3];
+    for (int a = 0; a < 3; a++) {
+        od[a] = out_dim(dims[a], ksize[a], stride[a]);
+        pad[a] = (ksize[a] - 1) / 2;
+    }
+    // one launch per output-parity class (1 class per stride-1 axis, 2 per stride-2 axis)
+    for (int pd = 0; pd < stride[0]; pd++)
+        for (int ph = 0; ph < stride[1]; ph++)
+            for (int pw = 0; pw < stride[2]; pw++) {
+                const int p[3] = {pd, ph, pw};
+                FwdGeom g;
+                memset(&g, 0, sizeof(g));
+                g.N = N;
+                g.Di = od[0]; g.Hi = od[1]; g.Wi = od[2];
+                g.Dy = D; g.Hy = H; g.Wy = W;
+                int grid[3];
+                bool empty = false;
+                for (int a = 0; a < 3; a++) {
+                    grid[a] = (dims[a] - p[a] + stride[a] - 1) / stride[a];
+                    if (grid[a] <= 0) empty = true;
+                    g.sa[a] = 1;
+                    g.so[a] = stride[a];
+                    g.oo[a] = p[a];
+                }
+                if (empty) continue;
+                g.Do = grid[0]; g.Ho = grid[1]; g.Wo = grid[2];
+                g.C1 = K; g.C2 = 0; g.K1 = C1; g.K2 = C2;
+                int nt = 0;
+                for (int ta = 0; ta < ksize[0]; ta++)
+                    for (int tb = 0; tb < ksize[1]; tb++)
+                        for (int tc = 0; tc < ksize[2]; tc++) {
+                            const int t3[3] = {ta, tb, tc};
+                            int off[3];
+                            bool ok = true;
+                            for (int a = 0; a < 3; a++) {
+                                int num = p[a] + pad[a] - t3[a];  // dy index q: q*s + t - pad = o*s + p
+                                if (num % stride[a] != 0) { ok = false; break; }
+                                off[a] = num / stride[a];
+                            }
+                            if (!ok) continue;
+                            for (int a = 0; a < 3; a++) g.off[nt][a] = (int8_t)off[a];
+                            g.wt[nt] = (int8_t)((ta * ksize[1] + tb) * ksize[2] + tc);
+                            nt++;
+                        }
+                g.ntaps = nt;
+                int r = run_fwd(g, dy, nullptr, wb, nullptr, dx1, dx2, as_stream(stream));
+                if (r) return r;
+            }
+    return 0;
+}
+
+static void conv_wgrad_geom(WgradGeom &g, int N, int D, int H, int W, int C1, int C2, int K, const int ks[3],
+                            const int st[3]) {
+    memset(&g, 0, sizeof(g));
+    g.N = N;
+    g.Di = D; g.Hi = H; g.Wi = W;
+    g.Do = out_dim(D, ks[0], st[0]); g.Ho = out_dim(H, ks[1], st[1]); g.Wo = out_dim(W, ks[2], st[2]);
+    g.Db = g.Do; g.Hb = g.Ho; g.Wb = g.Wo;
+    g.C1 = C1; g.C2 = C2; g.K = K;
+    int t = 0;
+    for (int a = 0; a < ks[0]; a++)
+        for (int b = 0; b < ks[1]; b++)
+            for (int c = 0; c < ks[2]; c++) {
+                g.off[t][0] = a - (ks[0] - 1) / 2;
+                g.off[t][1] = b - (ks[1] - 1) / 2;
+                g.off[t][2] = c - (ks[2] - 1) / 2;
+                g.wt[t] = t;
+                t++;
+            }
+    g.ntaps = g.T = t;
+    for (int a = 0; a < 3; a++) {
+        g.sa[a] = st[a];
+        g.sb[a] = 1;
+    }
+    g.transposed_out = 0;
+}
+
+size_t mvd_conv3d_wgrad_workspace_bytes(int C, int K, int T, int N, int Do, int Ho, int Wo) {
+    WgradGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.Do = Do; g.Ho = Ho; g.Wo = Wo; g.C1 = C; g.C2 = 0; g.K = K; g.ntaps = g.T = T;
+    size_t a = max_sz(wgrad_scalar_ws(g), wgrad_mfma_ws(g));
+    return max_sz(a, colsum_ws((long)N * Do * Ho * Wo, K));
+}
+
+int mvd_conv3d_wgrad(const float *x1, int C1, const float *x2, int C2, const float *dy, float *dw, float *dbias, int N,
+                     int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                     void *stream) {
+    MVD_REQUIRE(x1 && dy && dw && ws && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_wgrad: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_wgrad: bad shape");
+    if (check_ks(ksize, stride, "conv3d_wgrad")) return 2;
+    WgradGeom g;
+    conv_wgrad_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    MVD_REQUIRE(ws_bytes >= mvd_conv3d_wgrad_workspace_bytes(C1 + C2, K, g.T, N, g.Do, g.Ho, g.Wo),
+                "conv3d_wgrad: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (dbias) {
+        int r = colsum(dy, dbias, (long)N * g.Do * g.Ho * g.Wo, K, ws, s);
+        if (r) return r;
+    }
+    return run_wgrad(g, x1, x2, dy, dw, ws, ws_bytes, s);
+}
+
+// ------------------------------------------------------------------------------------------------ ConvTranspose3d k == s
+int mvd_convT3d_fwd(const float *x, const float *wf, const float *bias, float *y, int N, int D, int H, int W, int C, int K,
+                    const int stride[3], void *stream) {
+    MVD_REQUIRE(x && wf && y && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_fwd: bad arguments");
+    for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_fwd: stride must be 1 or 2");
+    for (int pd = 0; pd < stride[0]; pd++)
+        for (int ph = 0; ph < stride[1]; ph++)
+            for (int pw = 0; pw < stride[2]; pw++) {
+                FwdGeom g;
+                memset(&g, 0, sizeof(g));
+                g.N = N;
+                g.Di = g.Do = D; g.Hi = g.Ho = H; g.Wi = g.Wo = W;
+                g.Dy = D * stride[0]; g.Hy = H * stride[1]; g.Wy = W * stride[2];
+                g.C1 = C; g.K1 = K;
+                g.ntaps = 1;
+                g.wt[0] = (int8_t)((pd * stride[1] + ph) * stride[2] + pw);
+                const int p[3] = {pd, ph, pw};
+                for (int a = 0; a < 3; a++) {
+                    g.sa[a] = 1;
+                    g.so[a] = stride[a];
+                    g.oo[a] = p[a];
+                }
+                int r = run_fwd(g, x, nullptr, wf, bias, y, nullptr, as_stream(stream));
+                if (r) return r;
+            }
+    return 0;
+}
+
+int mvd_convT3d_dgrad(const float *dy, const float *wb, float *dx, int N, int D, int H, int W, int C, int K,
+                      const int stride[3], void *stream) {
+    MVD_REQUIRE(dy && wb && dx && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_dgrad: bad arguments");
+    for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_dgrad: stride must be 1 or 2");
+    FwdGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N;
+    g.Di = D * stride[0]; g.Hi = H * stride[1]; g.Wi = W * stride[2];
+    g.Do = g.Dy = D; g.Ho = g.Hy = H; g.Wo = g.Wy = W;
+    g.C1 = K; g.K1 = C;
+    int t = 0;
+    for (int pd = 0; pd < stride[0]; pd++)
+        for (int ph = 0; ph < stride[1]; ph++)
+            for (int pw = 0; pw < stride[2]; pw++) {
+                g.off[t][0] = pd; g.off[t][1] = ph; g.off[t][2] = pw;
+                g.wt[t] = t;
+                t++;
+            }
+    g.ntaps = t;
+    for (int a = 0; a < 3; a++) {
+        g.sa[a] = stride[a];
+        g.so[a] = 1;
+        g.oo[a] = 0;
+    }
+    return run_fwd(g, dy, nullptr, wb, nullptr, dx, nullptr, as_stream(stream));
+}
+
+static void convT_wgrad_geom(WgradGeom &g, int N, int D, int H, int W, int C, int K, const int st[3]) {
+    memset(&g, 0, sizeof(g));
+    g.N = N;
+    g.Di = g.Do = D; g.Hi = g.Ho = H; g.Wi = g.Wo = W;
+    g.Db = D * st[0]; g.Hb = H * st[1]; g.Wb = W * st[2];
+    g.C1 = C; g.C2 = 0; g.K = K;
+    int t = 0;
+    for (int pd = 0; pd < st[0]; pd++)
+        for (int ph = 0; ph < st[1]; ph++)
+            for (int pw = 0; pw < st[2]; pw++) {
+                g.ob[t][0] = pd; g.ob[t][1] = ph; g.ob[t][2] = pw;
+                g.wt[t] = t;
+                t++;
+            }
+    g.ntaps = g.T = t;
+    for (int a = 0; a < 3; a++) {
+        g.sa[a] = 1;
+        g.sb[a] = st[a];
+    }
+    g.transposed_out = 1;
+}
+
+size_t mvd_convT3d_wgrad_workspace_bytes(int C, int K, int T, int N, int D, int H, int W) {
+    WgradGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.Do = D; g.Ho = H; g.Wo = W; g.C1 = C; g.K = K; g.ntaps = g.T = T;
+    size_t a = max_sz(wgrad_scalar_ws(g), wgrad_mfma_ws(g));
+    return max_sz(a, colsum_ws((long)N * D * H * W * T, K));
+}
+
+int mvd_convT3d_wgrad(const float *x, const float *dy, float *dw, float *dbias, int N, int D, int H, int W, int C, int K,
+                      const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && dy && dw && ws && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_wgrad: bad arguments");
+    for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_wgrad: stride must be 1 or 2");
+    WgradGeom g;
+    convT_wgrad_geom(g, N, D, H, W, C, K, stride);
+    MVD_REQUIRE(ws_bytes >= mvd_convT3d_wgrad_workspace_bytes(C, K, g.T, N, D, H, W), "convT3d_wgrad: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (dbias) {
+        int r = colsum(dy, dbias, (long)N * g.Db * g.Hb * g.Wb, K, ws, s);
+        if (r) return r;
+    }
+    return run_wgrad(g, x, nullptr, dy, dw, ws, ws_bytes, s);
+}
+}

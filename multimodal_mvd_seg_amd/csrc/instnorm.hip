@@ -1,0 +1,339 @@
+// Fused InstanceNorm3d(affine) + LeakyReLU on NDHWC fp32 activations  (SURVEY K3/K4).
+// HBM-bound: fwd = read x (stats) + read x + write y; bwd = read x,dy (sums) + read x,dy + write dx.
+// Statistics: per-thread fp64 accumulation -> fixed-order LDS reduce -> per-block partials -> fixed-order finalize.
+#include "common.h"
+
+namespace mvd {
+
+struct NormGeom {
+    int C, CG, R, threads, nblk;
+    long V, chunk;
+};
+
+static NormGeom norm_geom(int N, long V, int C) {
+    NormGeom g;
+    g.C = C;
+    g.V = V;
+    int vec = (C % 4 == 0) ? 4 : 1;
+    g.CG = C / vec;
+    if (g.CG > 256) {  // very wide, not on the path; fall back to scalar columns of 256
+        g.CG = C;
+    }
+    g.R = 256 / g.CG;
+    if (g.R < 1) g.R = 1;
+    g.threads = ((g.R * g.CG + 63) / 64) * 64;
+    if (g.threads > 1024) g.threads = 1024;
+    long want = 2048 / (N > 0 ? N : 1);
+    if (want < 1) want = 1;
+    long rows_min = (long)g.R * 16;  // at least 16 voxels per thread
+    long nblk = V / rows_min;
+    if (nblk < 1) nblk = 1;
+    if (nblk > want) nblk = want;
+    g.nblk = (int)nblk;
+    g.chunk = cdiv(V, nblk);
+    return g;
+}
+
+// ---- pass 1 (fwd): partial[n][b][c][2] = (sum x, sum x^2) in fp64
+template <int VEC>
+__global__ void k_in_stats(const float *__restrict__ x, double *__restrict__ partial, int C, int CG, int R, long V,
+                           long chunk) {
+    extern __shared__ double sm[];  // [R][C][2]
+    const int n = blockIdx.y, b = blockIdx.x, nblk = gridDim.x;
+    const int t = threadIdx.x;
+    const int g = t % CG, r = t / CG;
+    const long v0 = (long)b * chunk;
+    long v1 = v0 + chunk;
+    if (v1 > V) v1 = V;
+    double s[VEC], ss[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) s[i] = ss[i] = 0.0;
+    if (r < R) {
+        const float *xp = x + ((size_t)n * V) * C + (size_t)g * VEC;
+        for (long v = v0 + r; v < v1; v += R) {
+            if (VEC == 4) {
+                float4 q = *reinterpret_cast<const float4 *>(xp + (size_t)v * C);
+                float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    s[i] += (double)f[i];
+                    ss[i] += (double)f[i] * (double)f[i];
+                }
+            } else {
+                float f = xp[(size_t)v * C];
+                s[0] += (double)f;
+                ss[0] += (double)f * (double)f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            sm[((size_t)r * C + g * VEC + i) * 2 + 0] = s[i];
+            sm[((size_t)r * C + g * VEC + i) * 2 + 1] = ss[i];
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) {
+        double a = 0, q = 0;
+        for (int rr = 0; rr < R; rr++) {
+            a += sm[((size_t)rr * C + c) * 2 + 0];
+            q += sm[((size_t)rr * C + c) * 2 + 1];
+        }
+        size_t o = (((size_t)n * nblk + b) * C + c) * 2;
+        partial[o] = a;
+        partial[o + 1] = q;
+    }
+}
+
+__global__ void k_in_finalize(const double *__restrict__ partial, float *__restrict__ mean, float *__restrict__ rstd,
+                              int C, int nblk, long V, float eps) {
+    int n = blockIdx.y;
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, q = 0;
+    for (int b = 0; b < nblk; b++) {
+        size_t o = (((size_t)n * nblk + b) * C + c) * 2;
+        a += partial[o];
+        q += partial[o + 1];
+    }
+    double m = a / (double)V;
+    double var = q / (double)V - m * m;
+    if (var < 0) var = 0;
+    mean[(size_t)n * C + c] = (float)m;
+    rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <int VEC>
+__global__ void k_in_apply(const float *__restrict__ x, const float *__restrict__ gamma,
+                           const float *__restrict__ beta, const float *__restrict__ mean,
+                           const float *__restrict__ rstd, float *__restrict__ y, int C, long V, float slope) {
+    const int n = blockIdx.y;
+    const long per_n = V * C / VEC;
+    const float *xn = x + (size_t)n * V * C;
+    float *yn = y + (size_t)n * V * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_n; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)((i * VEC) % C);
+        if (VEC == 4) {
+            float4 q = reinterpret_cast<const float4 *>(xn)[i];
+            float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float xh = (f[k] - mean[(size_t)n * C + c + k]) * rstd[(size_t)n * C + c + k];
+                float z = xh * gamma[c + k] + beta[c + k];
+                f[k] = z > 0.f ? z : z * slope;
+            }
+            reinterpret_cast<float4 *>(yn)[i] = make_float4(f[0], f[1], f[2], f[3]);
+        } else {
+            float xh = (xn[i] - mean[(size_t)n * C + c]) * rstd[(size_t)n * C + c];
+            float z = xh * gamma[c] + beta[c];
+            yn[i] = z > 0.f ? z : z * slope;
+        }
+    }
+}
+
+// ---- bwd pass 1: partial[n][b][c][2] = (sum dz, sum dz*xhat)
+template <int VEC>
+__global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restrict__ dy,
+                               const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ mean, const float *__restrict__ rstd,
+                               double *__restrict__ partial, int C, int CG, int R, long V, long chunk, float slope) {
+    extern __shared__ double sm[];
+    const int n = blockIdx.y, b = blockIdx.x, nblk = gridDim.x;
+    const int t = threadIdx.x;
+    const int g = t % CG, r = t / CG;
+    const long v0 = (long)b * chunk;
+    long v1 = v0 + chunk;
+    if (v1 > V) v1 = V;
+    double s[VEC], ss[VEC];
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) s[i] = ss[i] = 0.0;
+    if (r < R) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            int c = g * VEC + i;
+            mu[i] = mean[(size_t)n * C + c];
+            rs[i] = rstd[(size_t)n * C + c];
+            ga[i] = gamma[c];
+            be[i] = beta[c];
+        }
+        const size_t base = ((size_t)n * V) * C + (size_t)g * VEC;
+        for (long v = v0 + r; v < v1; v += R) {
+            float f[VEC], d[VEC];
+            if (VEC == 4) {
+                float4 q = *reinterpret_cast<const float4 *>(x + base + (size_t)v * C);
+                float4 e = *reinterpret_cast<const float4 *>(dy + base + (size_t)v * C);
+                f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+                d[0] = e.x; d[1] = e.y; d[2] = e.z; d[3] = e.w;
+            } else {
+                f[0] = x[base + (size_t)v * C];
+                d[0] = dy[base + (size_t)v * C];
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                float xh = (f[i] - mu[i]) * rs[i];
+                float z = xh * ga[i] + be[i];
+                float dz = z > 0.f ? d[i] : d[i] * slope;
+                s[i] += (double)dz;
+                ss[i] += (double)dz * (double)xh;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            sm[((size_t)r * C + g * VEC + i) * 2 + 0] = s[i];
+            sm[((size_t)r * C + g * VEC + i) * 2 + 1] = ss[i];
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) {
+        double a = 0, q = 0;
+        for (int rr = 0; rr < R; rr++) {
+            a += sm[((size_t)rr * C + c) * 2 + 0];
+            q += sm[((size_t)rr * C + c) * 2 + 1];
+        }
+        size_t o = (((size_t)n * nblk + b) * C + c) * 2;
+        partial[o] = a;
+        partial[o + 1] = q;
+    }
+}
+
+// sums[n][c][2] (float) = (sum dz, sum dz*xhat); dgamma/dbeta over n
+__global__ void k_in_bwd_finalize(const double *__restrict__ partial, float *__restrict__ sums,
+                                  float *__restrict__ dgamma, float *__restrict__ dbeta, int N, int C, int nblk) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double tg = 0, tb = 0;
+    for (int n = 0; n < N; n++) {
+        double a = 0, q = 0;
+        for (int b = 0; b < nblk; b++) {
+            size_t o = (((size_t)n * nblk + b) * C + c) * 2;
+            a += partial[o];
+            q += partial[o + 1];
+        }
+        sums[((size_t)n * C + c) * 2 + 0] = (float)a;
+        sums[((size_t)n * C + c) * 2 + 1] = (float)q;
+        tb += a;
+        tg += q;
+    }
+    dgamma[c] = (float)tg;
+    dbeta[c] = (float)tb;
+}
+
+template <int VEC>
+__global__ void k_in_bwd_apply(const float *__restrict__ x, const float *__restrict__ dy,
+                               const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ mean, const float *__restrict__ rstd,
+                               const float *__restrict__ sums, float *__restrict__ dx, int C, long V, float slope) {
+    const int n = blockIdx.y;
+    const long per_n = V * C / VEC;
+    const size_t off = (size_t)n * V * C;
+    const float invV = 1.0f / (float)V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_n; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)((i * VEC) % C);
+        float f[VEC], d[VEC];
+        if (VEC == 4) {
+            float4 q = reinterpret_cast<const float4 *>(x + off)[i];
+            float4 e = reinterpret_cast<const float4 *>(dy + off)[i];
+            f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+            d[0] = e.x; d[1] = e.y; d[2] = e.z; d[3] = e.w;
+        } else {
+            f[0] = x[off + i];
+            d[0] = dy[off + i];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; k++) {
+            size_t nc = (size_t)n * C + c + k;
+            float rs = rstd[nc];
+            float xh = (f[k] - mean[nc]) * rs;
+            float z = xh * gamma[c + k] + beta[c + k];
+            float dz = z > 0.f ? d[k] : d[k] * slope;
+            float m1 = sums[nc * 2 + 0] * invV, m2 = sums[nc * 2 + 1] * invV;
+            f[k] = gamma[c + k] * rs * (dz - m1 - xh * m2);
+        }
+        if (VEC == 4)
+            reinterpret_cast<float4 *>(dx + off)[i] = make_float4(f[0], f[1], f[2], f[3]);
+        else
+            dx[off + i] = f[0];
+    }
+}
+
+}  // namespace mvd
+
+using namespace mvd;
+
+extern "C" {
+
+int mvd_instnorm_nblk(int N, long V, int C) { return norm_geom(N, V, C).nblk; }
+
+size_t mvd_instnorm_workspace_bytes(int N, long V, int C) {
+    NormGeom g = norm_geom(N, V, C);
+    // partials (doubles) + sums [N][C][2] floats
+    return (size_t)N * g.nblk * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float) + 256;
+}
+
+int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                           int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "instnorm_fwd: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C <= 1024, "instnorm_fwd: bad shape N=%d V=%ld C=%d", N, V, C);
+    MVD_REQUIRE(ws_bytes >= mvd_instnorm_workspace_bytes(N, V, C), "instnorm_fwd: workspace too small");
+    NormGeom g = norm_geom(N, V, C);
+    hipStream_t s = as_stream(stream);
+    double *partial = reinterpret_cast<double *>(ws);
+    size_t sm = (size_t)g.R * C * 2 * sizeof(double);
+    MVD_REQUIRE(sm <= 64 * 1024, "instnorm_fwd: C too large for the LDS reduce");
+    const bool v4 = (C % 4 == 0) && (g.CG * 4 == C);
+    dim3 grid(g.nblk, N);
+    if (v4)
+        hipLaunchKernelGGL(k_in_stats<4>, grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+    else
+        hipLaunchKernelGGL(k_in_stats<1>, grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+    if (check_launch("instnorm stats")) return 1;
+    hipLaunchKernelGGL(k_in_finalize, dim3(cdiv(C, 64), N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
+    if (check_launch("instnorm finalize")) return 1;
+    long per_n = V * C / (v4 ? 4 : 1);
+    long bx = cdiv(per_n, 256);
+    long cap = 4096 / N > 0 ? 4096 / N : 1;
+    if (bx > cap) bx = cap;
+    if (v4)
+        hipLaunchKernelGGL(k_in_apply<4>, dim3(bx, N), dim3(256), 0, s, x, gamma, beta, mean, rstd, y, C, V, slope);
+    else
+        hipLaunchKernelGGL(k_in_apply<1>, dim3(bx, N), dim3(256), 0, s, x, gamma, beta, mean, rstd, y, C, V, slope);
+    return check_launch("instnorm apply");
+}
+
+int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *mean,
+                           const float *rstd, float *dx, float *dgamma, float *dbeta, int N, long V, int C,
+                           float slope, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta && ws, "instnorm_bwd: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C <= 1024, "instnorm_bwd: bad shape");
+    MVD_REQUIRE(ws_bytes >= mvd_instnorm_workspace_bytes(N, V, C), "instnorm_bwd: workspace too small");
+    NormGeom g = norm_geom(N, V, C);
+    hipStream_t s = as_stream(stream);
+    double *partial = reinterpret_cast<double *>(ws);
+    float *sums = reinterpret_cast<float *>(partial + (size_t)N * g.nblk * C * 2);
+    size_t sm = (size_t)g.R * C * 2 * sizeof(double);
+    MVD_REQUIRE(sm <= 64 * 1024, "instnorm_bwd: C too large for the LDS reduce");
+    const bool v4 = (C % 4 == 0) && (g.CG * 4 == C);
+    dim3 grid(g.nblk, N);
+    if (v4)
+        hipLaunchKernelGGL(k_in_bwd_stats<4>, grid, dim3(g.threads), sm, s, x, dy, gamma, beta, mean, rstd, partial, C,
+                           g.CG, g.R, V, g.chunk, slope);
+    else
+        hipLaunchKernelGGL(k_in_bwd_stats<1>, grid, dim3(g.threads), sm, s, x, dy, gamma, beta, mean, rstd, partial, C,
+                           g.CG, g.R, V, g.chunk, slope);
+    if (check_launch("instnorm bwd stats")) return 1;
+    hipLaunchKernelGGL(k_in_bwd_finalize, dim3(cdiv(C, 64)), dim3(64), 0, s, partial, sums, dgamma, dbeta, N, C,
+                       g.nblk);
+    if (check_launch("instnorm bwd finalize")) return 1;
+    long per_n = V * C / (v4 ? 4 : 1);
+    long bx = cdiv(per_n, 256);
+    long cap = 4096 / N > 0 ? 4096 / N : 1;
+    if (bx > cap) bx = cap;
+    if (v4)
+        hipLaunchKernelGGL(k_in_bwd_apply<4>, dim3(bx, N), dim3(256), 0, s, x, dy, gamma, beta, mean, rstd, sums, dx, C,
+                           V, slope);
+    else
+        hipLaunchKernelGGL(k_in_bwd_apply<1>, dim3(bx, N), dim3(256), 0, s, x, dy, gamma, beta, mean, rstd, sums, dx, C,
+                           V, slope);
+    return check_launch("instnorm bwd apply");
+}
+}

@@ -1,0 +1,619 @@
+// Segmentation head (1x1x1 conv NDHWC -> planar logits), fused softmax+CE+soft-Dice, argmax counts, KL distillation.
+// All HBM-bound single-pass kernels; reductions are fp64 per thread -> fixed-order block tree -> partials -> finalize.
+#include "common.h"
+
+namespace mvd {
+
+constexpr int KMAX = 8;    // classes (K = 5 on the reference's data, MVDTrainer.py:98)
+constexpr int KLCMAX = 32; // channels of the KL softmax (logits <= 8, features 32)
+
+// =============================================================================================== seg head fwd
+// block: 256 threads = 64 voxels x 4 class slots; channels staged through LDS in chunks of 32 (coalesced 128-B rows)
+__global__ void k_seghead_fwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                              float *__restrict__ logits, long V, int C, int K) {
+    __shared__ float tile[64][33];
+    const int n = blockIdx.y;
+    const long v0 = (long)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int vox = t & 63, kq = t >> 6;
+    float acc[2] = {0.f, 0.f};
+    const float *xn = x + (size_t)n * V * C;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        __syncthreads();
+        for (int j = t; j < 64 * 32; j += 256) {
+            int vv = j >> 5, ch = j & 31;
+            long v = v0 + vv;
+            tile[vv][ch] = (v < V && c0 + ch < C) ? xn[(size_t)v * C + c0 + ch] : 0.f;
+        }
+        __syncthreads();
+        const int cn = (C - c0 < 32) ? (C - c0) : 32;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int k = kq + 4 * i;
+            if (k < K) {
+                const float *wk = w + (size_t)k * C + c0;
+                float a = acc[i];
+                for (int ch = 0; ch < cn; ch++) a += tile[vox][ch] * wk[ch];
+                acc[i] = a;
+            }
+        }
+    }
+    long v = v0 + vox;
+    if (v < V) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int k = kq + 4 * i;
+            if (k < K) logits[((size_t)n * K + k) * V + v] = acc[i] + bias[k];
+        }
+    }
+}
+
+// dx[n][v][c] (+)= sum_k dl[n][k][v] * w[k][c]
+__global__ void k_seghead_dx(const float *__restrict__ dl, const float *__restrict__ w, float *__restrict__ dx, long V,
+                             int C, int K, int accumulate) {
+    extern __shared__ float sm[];  // w_s[K][C], dl_s[K][64]
+    float *w_s = sm;
+    float *dl_s = sm + (size_t)K * C;
+    const int n = blockIdx.y;
+    const long v0 = (long)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    for (int j = t; j < K * C; j += 256) w_s[j] = w[j];
+    for (int j = t; j < K * 64; j += 256) {
+        int k = j >> 6, vv = j & 63;
+        long v = v0 + vv;
+        dl_s[j] = (v < V) ? dl[((size_t)n * K + k) * V + v] : 0.f;
+    }
+    __syncthreads();
+    float *dxn = dx + ((size_t)n * V + v0) * C;
+    const long nv = (V - v0 < 64) ? (V - v0) : 64;
+    for (long j = t; j < nv * C; j += 256) {
+        int vv = (int)(j / C), c = (int)(j % C);
+        float a = 0.f;
+        for (int k = 0; k < K; k++) a += dl_s[k * 64 + vv] * w_s[k * C + c];
+        dxn[j] = accumulate ? dxn[j] + a : a;
+    }
+}
+
+// partial[b][k*C + c] = sum over the block's voxels of dl[k][v]*x[v][c]; partial[b][K*C + k] = sum dl[k][v]
+__global__ void k_seghead_dw(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
+                             int N, long V, int C, int K, long chunk) {
+    __shared__ float xs[64][33];
+    __shared__ float ds[KMAX][64];
+    const int t = threadIdx.x;
+    const int c_l = t & 31, kq = t >> 5;  // 32 channels x 8 class slots
+    const long total = (long)N * V;
+    const long g0 = (long)blockIdx.x * chunk;
+    long g1 = g0 + chunk;
+    if (g1 > total) g1 = total;
+    const int nv_out = K * C + K;
+    double *po = partial + (size_t)blockIdx.x * nv_out;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        double acc = 0.0, accb = 0.0;
+        for (long base = g0; base < g1; base += 64) {
+            __syncthreads();
+            for (int j = t; j < 64 * 32; j += 256) {
+                int vv = j >> 5, ch = j & 31;
+                long g = base + vv;
+                xs[vv][ch] = (g < g1 && c0 + ch < C) ? x[(size_t)g * C + c0 + ch] : 0.f;
+            }
+            for (int j = t; j < K * 64; j += 256) {
+                int k = j >> 6, vv = j & 63;
+                long g = base + vv;
+                float val = 0.f;
+                if (g < g1) {
+                    long n = g / V, v = g % V;
+                    val = dl[((size_t)n * K + k) * V + v];
+                }
+                ds[k][vv] = val;
+            }
+            __syncthreads();
+            if (kq < K) {
+                float a = 0.f, b = 0.f;
+#pragma unroll 8
+                for (int vv = 0; vv < 64; vv++) {
+                    a += ds[kq][vv] * xs[vv][c_l];
+                    b += ds[kq][vv];
+                }
+                acc += (double)a;
+                accb += (double)b;
+            }
+        }
+        if (kq < K && c0 + c_l < C) po[(size_t)kq * C + c0 + c_l] = acc;
+        if (c0 == 0 && kq < K && c_l == 0) po[(size_t)K * C + kq] = accb;
+    }
+}
+
+// =============================================================================================== DC + CE
+__device__ inline int label_of(float t, int K) {
+    int y = (int)t;  // .long() truncation (robust_ce_loss.py:16)
+    return y < 0 ? 0 : (y >= K ? K - 1 : y);
+}
+
+__global__ void k_dcce_fwd(const float *__restrict__ logits, const float *__restrict__ target,
+                           double *__restrict__ partial, int N, long V, int K) {
+    __shared__ double red[(3 * KMAX + 1) * 16];
+    const int n = blockIdx.y;
+    const float *ln = logits + (size_t)n * K * V;
+    const float *tn = target + (size_t)n * V;
+    double acc[3 * KMAX + 1];
+#pragma unroll
+    for (int i = 0; i < 3 * KMAX + 1; i++) acc[i] = 0.0;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float z[KMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                z[k] = ln[(size_t)k * V + v];
+                m = fmaxf(m, z[k]);
+            }
+        const int y = label_of(tn[v], K);
+        float s = 0.f, zy = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                float d = z[k] - m;
+                if (k == y) zy = d;
+                z[k] = expf(d);
+                s += z[k];
+            }
+        const float inv = 1.0f / s;
+        acc[3 * KMAX] += (double)(logf(s) - zy);  // -log_softmax(z)[y]
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                float p = z[k] * inv;
+                if (k == y) {
+                    acc[3 * k + 0] += (double)p;
+                    acc[3 * k + 2] += 1.0;
+                }
+                acc[3 * k + 1] += (double)p;
+            }
+    }
+    block_sum<3 * KMAX + 1>(acc, red);
+    if (threadIdx.x == 0) {
+        // partial[b][n][3K+1]
+        double *po = partial + ((size_t)blockIdx.x * N + n) * (3 * K + 1);
+        for (int k = 0; k < K; k++) {
+            po[3 * k + 0] = acc[3 * k + 0];
+            po[3 * k + 1] = acc[3 * k + 1];
+            po[3 * k + 2] = acc[3 * k + 2];
+        }
+        po[3 * K] = acc[3 * KMAX];
+    }
+}
+
+__global__ void k_dcce_finalize(const float *__restrict__ stats, int N, const float *__restrict__ dstats, int Nd,
+                                float *__restrict__ loss, float *__restrict__ coef, long V, int K, int batch_dice,
+                                int do_bg, float smooth, float w_ce, float w_dice) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int S = 3 * K + 1;
+    double ce = 0;
+    for (int n = 0; n < N; n++) ce += (double)stats[(size_t)n * S + 3 * K];
+    ce /= ((double)N * (double)V);
+    const int k0 = do_bg ? 0 : 1;
+    double dcsum = 0;
+    for (size_t i = 0; i < (size_t)Nd * K * 2; i++) coef[i] = 0.f;
+    if (batch_dice) {
+        const double cnt = (double)(K - k0);
+        for (int k = k0; k < K; k++) {
+            float I = 0, P = 0, G = 0;  // torch sums the per-sample fp32 values in fp32
+            for (int n = 0; n < Nd; n++) {
+                I += dstats[(size_t)n * S + 3 * k + 0];
+                P += dstats[(size_t)n * S + 3 * k + 1];
+                G += dstats[(size_t)n * S + 3 * k + 2];
+            }
+            float den = G + P + smooth;
+            bool clipped = den < 1e-8f;
+            if (clipped) den = 1e-8f;
+            float num = 2.f * I + smooth;
+            dcsum += (double)(num / den);
+            float cI = (float)(-(1.0 / cnt) * 2.0 / (double)den);
+            float cP = clipped ? 0.f : (float)((1.0 / cnt) * (double)num / ((double)den * (double)den));
+            for (int n = 0; n < Nd; n++) {
+                coef[((size_t)n * K + k) * 2 + 0] = w_dice * cI;
+                coef[((size_t)n * K + k) * 2 + 1] = w_dice * cP;
+            }
+        }
+        dcsum /= cnt;
+    } else {
+        const double cnt = (double)Nd * (double)(K - k0);
+        for (int n = 0; n < Nd; n++)
+            for (int k = k0; k < K; k++) {
+                float I = dstats[(size_t)n * S + 3 * k + 0], P = dstats[(size_t)n * S + 3 * k + 1],
+                      G = dstats[(size_t)n * S + 3 * k + 2];
+                float den = G + P + smooth;
+                bool clipped = den < 1e-8f;
+                if (clipped) den = 1e-8f;
+                float num = 2.f * I + smooth;
+                dcsum += (double)(num / den);
+                coef[((size_t)n * K + k) * 2 + 0] = w_dice * (float)(-(1.0 / cnt) * 2.0 / (double)den);
+                coef[((size_t)n * K + k) * 2 + 1] =
+                    clipped ? 0.f : w_dice * (float)((1.0 / cnt) * (double)num / ((double)den * (double)den));
+            }
+        dcsum /= cnt;
+    }
+    loss[1] = (float)ce;
+    loss[2] = (float)(-dcsum);
+    loss[0] = w_ce * (float)ce + w_dice * (float)(-dcsum);
+}
+
+__global__ void k_dcce_bwd(const float *__restrict__ logits, const float *__restrict__ target,
+                           const float *__restrict__ coef, const float *__restrict__ gscale_dev, float gscale_host,
+                           float *__restrict__ dlogits, int N, long V, int K, float w_ce) {
+    const int n = blockIdx.y;
+    const float *ln = logits + (size_t)n * K * V;
+    const float *tn = target + (size_t)n * V;
+    float *dn = dlogits + (size_t)n * K * V;
+    const float g = gscale_host * (gscale_dev ? gscale_dev[0] : 1.0f);
+    const float cew = w_ce / ((float)N * (float)V);
+    float cI[KMAX], cP[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+            cI[k] = coef[((size_t)n * K + k) * 2 + 0];
+            cP[k] = coef[((size_t)n * K + k) * 2 + 1];
+        }
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float z[KMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                z[k] = ln[(size_t)k * V + v];
+                m = fmaxf(m, z[k]);
+            }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                z[k] = expf(z[k] - m);
+                s += z[k];
+            }
+        const float inv = 1.0f / s;
+        const int y = label_of(tn[v], K);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                z[k] *= inv;  // p_k
+                float q = cP[k] + (k == y ? cI[k] : 0.f);
+                dot += z[k] * q;
+            }
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                float q = cP[k] + (k == y ? cI[k] : 0.f);
+                float d = cew * (z[k] - (k == y ? 1.f : 0.f)) + z[k] * (q - dot);
+                dn[(size_t)k * V + v] = g * d;
+            }
+    }
+}
+
+__global__ void k_argmax_counts(const float *__restrict__ logits, const float *__restrict__ target,
+                                unsigned long long *__restrict__ counts, long V, int K) {
+    __shared__ unsigned int c_s[KMAX * 3];
+    const int n = blockIdx.y;
+    if (threadIdx.x < KMAX * 3) c_s[threadIdx.x] = 0;
+    __syncthreads();
+    const float *ln = logits + (size_t)n * K * V;
+    const float *tn = target + (size_t)n * V;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        int best = 0;
+        float bv = ln[v];
+        for (int k = 1; k < K; k++) {
+            float z = ln[(size_t)k * V + v];
+            if (z > bv) {  // first maximum wins (torch.argmax)
+                bv = z;
+                best = k;
+            }
+        }
+        int y = label_of(tn[v], K);
+        if (best == y)
+            atomicAdd(&c_s[3 * y + 0], 1u);
+        else {
+            atomicAdd(&c_s[3 * best + 1], 1u);
+            atomicAdd(&c_s[3 * y + 2], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < K * 3 && c_s[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)c_s[threadIdx.x]);
+}
+
+// =============================================================================================== softmax channel select
+template <bool BWD>
+__global__ void k_softmax_select(const float *__restrict__ logits, const float *__restrict__ g, float *__restrict__ out,
+                                 long V, int K, int sel) {
+    const int n = blockIdx.y;
+    const float *ln = logits + (size_t)n * K * V;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float z[KMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                z[k] = ln[(size_t)k * V + v];
+                m = fmaxf(m, z[k]);
+            }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                z[k] = expf(z[k] - m);
+                s += z[k];
+            }
+        const float inv = 1.0f / s;
+        float ps = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k == sel) ps = z[k] * inv;
+        if (!BWD) {
+            out[(size_t)n * V + v] = ps;
+        } else {
+            const float gg = g[(size_t)n * V + v] * ps;
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                if (k < K) out[((size_t)n * K + k) * V + v] = gg * ((k == sel ? 1.f : 0.f) - z[k] * inv);
+        }
+    }
+}
+
+__global__ void k_label_mask(const float *__restrict__ labels, float *__restrict__ mask, long n, float value) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        mask[i] = (labels[i] == value) ? 1.f : 0.f;
+}
+
+// =============================================================================================== KL distillation
+struct KlIdx {
+    long sn, sc, sv;
+};
+
+template <bool BWD>
+__global__ void k_kl(const float *__restrict__ ys, const float *__restrict__ yt, double *__restrict__ partial,
+                     float *__restrict__ gs, float *__restrict__ gt, const float *__restrict__ gscale_dev,
+                     float gscale_host, int N, int C, long V, KlIdx ix, float T, float eps_s, int pad) {
+    __shared__ double red[16];
+    const int Ce = pad ? C + 1 : C;
+    const float invT = 1.0f / T;
+    const double coef = (double)T * (double)T / ((double)N * (double)Ce * (double)V);
+    const float g = BWD ? gscale_host * (gscale_dev ? gscale_dev[0] : 1.0f) * (float)coef * invT : 0.f;
+    double acc[1] = {0.0};
+    const long total = (long)N * V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / V, v = i % V;
+        const size_t base = (size_t)n * ix.sn + (size_t)v * ix.sv;
+        float a[KLCMAX + 1], b[KLCMAX + 1];
+        float ma = -INFINITY, mb = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < KLCMAX + 1; c++)
+            if (c < Ce) {
+                float s_ = (c < C) ? ys[base + (size_t)c * ix.sc] : 0.f;
+                float t_ = (c < C) ? yt[base + (size_t)c * ix.sc] : 0.f;
+                a[c] = s_ * invT + eps_s;
+                b[c] = t_ * invT;
+                ma = fmaxf(ma, a[c]);
+                mb = fmaxf(mb, b[c]);
+            }
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int c = 0; c < KLCMAX + 1; c++)
+            if (c < Ce) {
+                sa += expf(a[c] - ma);
+                sb += expf(b[c] - mb);
+            }
+        const float lsa = logf(sa), lsb = logf(sb);
+        float kl = 0.f;
+#pragma unroll
+        for (int c = 0; c < KLCMAX + 1; c++)
+            if (c < Ce) {
+                float lq = a[c] - ma - lsa;  // log_softmax(student)
+                float lp = b[c] - mb - lsb;  // log softmax(teacher)
+                float p = expf(lp);
+                float d = lp - lq;
+                kl += (p > 0.f) ? p * d : 0.f;
+                if (BWD) {
+                    a[c] = expf(lq) - p;  // dL/du_s (times 1/T folded in g)
+                    b[c] = d;             // c_j
+                }
+            }
+        if (BWD) {
+            if (gs) {
+#pragma unroll
+                for (int c = 0; c < KLCMAX; c++)
+                    if (c < C) gs[base + (size_t)c * ix.sc] = g * a[c];
+            }
+            if (gt) {
+                // p_k (c_k - sum_j p_j c_j); p_j = q_j - a_j ... recompute p from lp: p = exp(lp)
+                float dot = kl;  // sum_j p_j c_j
+#pragma unroll
+                for (int c = 0; c < KLCMAX; c++)
+                    if (c < C) {
+                        float lp = (yt[base + (size_t)c * ix.sc] * invT) - mb - lsb;
+                        float p = expf(lp);
+                        gt[base + (size_t)c * ix.sc] = g * p * (b[c] - dot);
+                    }
+            }
+        } else {
+            acc[0] += (double)kl;
+        }
+    }
+    if (!BWD) {
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = acc[0] * coef;
+    }
+}
+
+}  // namespace mvd
+
+using namespace mvd;
+
+static inline long grid_for(long n, long cap) {
+    long b = cdiv(n, 256);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return b;
+}
+static inline long cap_per_n(long total_blocks, int N) {
+    long c = total_blocks / (N > 0 ? N : 1);
+    return c > 0 ? c : 1;
+}
+
+extern "C" {
+
+int mvd_seghead_fwd(const float *x, const float *w, const float *bias, float *logits, int N, long V, int C, int K,
+                    void *stream) {
+    MVD_REQUIRE(x && w && bias && logits, "seghead_fwd: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && K > 0 && K <= KMAX, "seghead_fwd: bad shape (K<=8)");
+    hipLaunchKernelGGL(k_seghead_fwd, dim3(cdiv(V, 64), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C,
+                       K);
+    return check_launch("seghead_fwd");
+}
+
+static long seghead_chunk(long total, int *nblk) {
+    long nb = total / 2048;
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    long chunk = cdiv(total, nb);
+    chunk = cdiv(chunk, 64) * 64;
+    *nblk = (int)cdiv(total, chunk);
+    return chunk;
+}
+
+size_t mvd_seghead_bwd_workspace_bytes(int N, long V, int C, int K) {
+    int nblk;
+    seghead_chunk((long)N * V, &nblk);
+    return (size_t)nblk * (K * C + K) * sizeof(double) + 256;
+}
+
+int mvd_seghead_bwd(const float *x, const float *w, const float *dlogits, float *dx, float *dw, float *dbias, int N,
+                    long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && w && dlogits && ws, "seghead_bwd: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && K > 0 && K <= KMAX, "seghead_bwd: bad shape (K<=8)");
+    MVD_REQUIRE(ws_bytes >= mvd_seghead_bwd_workspace_bytes(N, V, C, K), "seghead_bwd: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (dx) {
+        size_t sm = ((size_t)K * C + (size_t)K * 64) * sizeof(float);
+        hipLaunchKernelGGL(k_seghead_dx, dim3(cdiv(V, 64), N), dim3(256), sm, s, dlogits, w, dx, V, C, K, accumulate);
+        if (check_launch("seghead_dx")) return 1;
+    }
+    if (dw) {
+        MVD_REQUIRE(dbias, "seghead_bwd: dbias required with dw");
+        int nblk;
+        long chunk = seghead_chunk((long)N * V, &nblk);
+        double *partial = reinterpret_cast<double *>(ws);
+        hipLaunchKernelGGL(k_seghead_dw, dim3(nblk), dim3(256), 0, s, x, dlogits, partial, N, V, C, K, chunk);
+        if (check_launch("seghead_dw")) return 1;
+        // outputs [K*C] then [K]: dw and dbias are separate buffers -> two reduces over the same partials
+        if (reduce_partials(partial, dw, nblk, K * C, s, K * C + K, 0)) return 1;
+        if (reduce_partials(partial, dbias, nblk, K, s, K * C + K, K * C)) return 1;
+    }
+    return 0;
+}
+
+size_t mvd_dcce_workspace_bytes(int N, long V, int K) {
+    long bx = grid_for(V, cap_per_n(2048, N));
+    return (size_t)bx * N * (3 * K + 1) * sizeof(double) + 256;
+}
+
+int mvd_dcce_fwd(const float *logits, const float *target, float *stats, int N, long V, int K, void *ws, size_t ws_bytes,
+                 void *stream) {
+    MVD_REQUIRE(logits && target && stats && ws, "dcce_fwd: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && K >= 2 && K <= KMAX, "dcce_fwd: bad shape (2<=K<=8)");
+    MVD_REQUIRE(ws_bytes >= mvd_dcce_workspace_bytes(N, V, K), "dcce_fwd: workspace too small");
+    long bx = grid_for(V, cap_per_n(2048, N));
+    double *partial = reinterpret_cast<double *>(ws);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_dcce_fwd, dim3(bx, N), dim3(256), 0, s, logits, target, partial, N, V, K);
+    if (check_launch("dcce_fwd")) return 1;
+    return reduce_partials(partial, stats, (int)bx, N * (3 * K + 1), s);
+}
+
+int mvd_dcce_finalize(const float *stats, int N, const float *dstats, int Nd, float *loss, float *coef, long V, int K,
+                      int batch_dice, int do_bg, float smooth, float w_ce, float w_dice, void *stream) {
+    MVD_REQUIRE(stats && loss && coef && N > 0 && K >= 2 && K <= KMAX, "dcce_finalize: bad arguments");
+    if (!dstats) {
+        dstats = stats;
+        Nd = N;
+    }
+    hipLaunchKernelGGL(k_dcce_finalize, dim3(1), dim3(64), 0, as_stream(stream), stats, N, dstats, Nd, loss, coef, V, K,
+                       batch_dice, do_bg, smooth, w_ce, w_dice);
+    return check_launch("dcce_finalize");
+}
+
+int mvd_dcce_bwd(const float *logits, const float *target, const float *coef, const float *gscale_dev, float gscale_host,
+                 float *dlogits, int N, long V, int K, float w_ce, void *stream) {
+    MVD_REQUIRE(logits && target && coef && dlogits, "dcce_bwd: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && K >= 2 && K <= KMAX, "dcce_bwd: bad shape");
+    long bx = grid_for(V, cap_per_n(4096, N));
+    hipLaunchKernelGGL(k_dcce_bwd, dim3(bx, N), dim3(256), 0, as_stream(stream), logits, target, coef, gscale_dev,
+                       gscale_host, dlogits, N, V, K, w_ce);
+    return check_launch("dcce_bwd");
+}
+
+int mvd_argmax_counts(const float *logits, const float *target, long long *counts, int N, long V, int K, void *stream) {
+    MVD_REQUIRE(logits && target && counts, "argmax_counts: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && K >= 1 && K <= KMAX, "argmax_counts: bad shape");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(counts, 0, sizeof(long long) * K * 3, s) != hipSuccess) {
+        set_error("argmax_counts: memset failed");
+        return 1;
+    }
+    long bx = grid_for(V, cap_per_n(1024, N));
+    hipLaunchKernelGGL(k_argmax_counts, dim3(bx, N), dim3(256), 0, s, logits, target,
+                       reinterpret_cast<unsigned long long *>(counts), V, K);
+    return check_launch("argmax_counts");
+}
+
+int mvd_softmax_select_fwd(const float *logits, float *p_sel, int N, long V, int K, int sel, void *stream) {
+    MVD_REQUIRE(logits && p_sel && N > 0 && N <= 65535 && V > 0 && K >= 1 && K <= KMAX && sel >= 0 && sel < K,
+                "softmax_select_fwd: bad arguments");
+    long bx = grid_for(V, cap_per_n(4096, N));
+    hipLaunchKernelGGL(k_softmax_select<false>, dim3(bx, N), dim3(256), 0, as_stream(stream), logits, nullptr, p_sel, V,
+                       K, sel);
+    return check_launch("softmax_select_fwd");
+}
+int mvd_softmax_select_bwd(const float *logits, const float *g, float *dlogits, int N, long V, int K, int sel,
+                           void *stream) {
+    MVD_REQUIRE(logits && g && dlogits && N > 0 && N <= 65535 && V > 0 && K >= 1 && K <= KMAX && sel >= 0 && sel < K,
+                "softmax_select_bwd: bad arguments");
+    long bx = grid_for(V, cap_per_n(4096, N));
+    hipLaunchKernelGGL(k_softmax_select<true>, dim3(bx, N), dim3(256), 0, as_stream(stream), logits, g, dlogits, V, K,
+                       sel);
+    return check_launch("softmax_select_bwd");
+}
+int mvd_label_mask(const float *labels, float *mask, long n, float value, void *stream) {
+    MVD_REQUIRE(labels && mask && n > 0, "label_mask: bad arguments");
+    hipLaunchKernelGGL(k_label_mask, dim3(grid_for(n, 4096)), dim3(256), 0, as_stream(stream), labels, mask, n, value);
+    return check_launch("label_mask");
+}
+
+size_t mvd_kl_workspace_bytes(int N, long V) { return (size_t)grid_for((long)N * V, 2048) * sizeof(double) + 256; }
+
+int mvd_kl_fwd(const float *ys, const float *yt, float *out, int N, int C, long V, long sn, long sc, long sv, float T,
+               float eps_s, int pad, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(ys && yt && out && ws, "kl_fwd: null pointer");
+    MVD_REQUIRE(N > 0 && V > 0 && C >= 1 && C <= KLCMAX && T > 0, "kl_fwd: bad shape (C<=32)");
+    MVD_REQUIRE(!pad || C == 1, "kl_fwd: zero-channel padding is the C==1 branch");
+    MVD_REQUIRE(ws_bytes >= mvd_kl_workspace_bytes(N, V), "kl_fwd: workspace too small");
+    long bx = grid_for((long)N * V, 2048);
+    double *partial = reinterpret_cast<double *>(ws);
+    KlIdx ix{sn, sc, sv};
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_kl<false>, dim3(bx), dim3(256), 0, s, ys, yt, partial, nullptr, nullptr, nullptr, 1.f, N, C, V,
+                       ix, T, eps_s, pad);
+    if (check_launch("kl_fwd")) return 1;
+    return reduce_partials(partial, out, (int)bx, 1, s);
+}
+
+int mvd_kl_bwd(const float *ys, const float *yt, const float *gscale_dev, float gscale_host, float *gs, float *gt, int N,
+               int C, long V, long sn, long sc, long sv, float T, float eps_s, int pad, void *stream) {
+    MVD_REQUIRE(ys && yt && (gs || gt), "kl_bwd: null pointer");
+    MVD_REQUIRE(N > 0 && V > 0 && C >= 1 && C <= KLCMAX && T > 0, "kl_bwd: bad shape (C<=32)");
+    MVD_REQUIRE(!pad || C == 1, "kl_bwd: zero-channel padding is the C==1 branch");
+    long bx = grid_for((long)N * V, 4096);
+    KlIdx ix{sn, sc, sv};
+    hipLaunchKernelGGL(k_kl<true>, dim3(bx), dim3(256), 0, as_stream(stream), ys, yt, nullptr, gs, gt, gscale_dev,
+                       gscale_host, N, C, V, ix, T, eps_s, pad);
+    return check_launch("kl_bwd");
+}
+}

@@ -1,0 +1,440 @@
+// Soft-skeleton primitives (erode / dilate / skeleton update) on planar volumes and the integer
+// connected-component labelling (K12).  Compiled with -ffp-contract=off: `delta - skel*delta` must round the product
+// (torch does mul then sub) for bit-exact forward parity.
+#include "common.h"
+
+namespace mvd {
+
+// ------------------------------------------------------------------------------------------------ erode
+// code bits: [1:0] argmin pos along D (0,1,2 = d-1,d,d+1), [3:2] along H, [5:4] along W,
+//            [7:6] p1 vs p2 (0: p1<p2, 1: equal, 2: p1>p2), [9:8] min(p1,p2) vs p3 (same encoding)
+__device__ inline float axis_min(const float *p, long stride, int pos, int len, int &arg) {
+    // first minimum in scan order (-F.max_pool3d(-x) keeps the first maximum, soft_skeleton.py:12-14)
+    float best = INFINITY;
+    arg = 1;
+    bool have = false;
+#pragma unroll
+    for (int o = -1; o <= 1; o++) {
+        int q = pos + o;
+        if (q < 0 || q >= len) continue;
+        float v = p[(long)o * stride];
+        if (!have || v < best) {
+            best = v;
+            arg = o + 1;
+            have = true;
+        }
+    }
+    return best;
+}
+
+__global__ void k_erode_fwd(const float *__restrict__ x, float *__restrict__ y, uint16_t *__restrict__ code, long total,
+                            int D, int H, int W) {
+    const long HW = (long)H * W, DHW = (long)D * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i % DHW;
+        int d = (int)(r / HW), h = (int)((r % HW) / W), w = (int)(r % W);
+        int a1, a2, a3;
+        float p1 = axis_min(x + i, HW, d, D, a1);
+        float p2 = axis_min(x + i, W, h, H, a2);
+        float p3 = axis_min(x + i, 1, w, W, a3);
+        float m12 = fminf(p1, p2);
+        y[i] = fminf(m12, p3);
+        if (code) {
+            int c12 = p1 < p2 ? 0 : (p1 == p2 ? 1 : 2);
+            int c3 = m12 < p3 ? 0 : (m12 == p3 ? 1 : 2);
+            code[i] = (uint16_t)(a1 | (a2 << 2) | (a3 << 4) | (c12 << 6) | (c3 << 8));
+        }
+    }
+}
+
+__device__ inline void erode_shares(uint16_t c, float s[3]) {
+    int c12 = (c >> 6) & 3, c3 = (c >> 8) & 3;
+    float sm = c3 == 0 ? 1.f : (c3 == 1 ? 0.5f : 0.f);  // share of min(p1,p2)
+    s[2] = 1.f - sm;
+    float s1 = c12 == 0 ? 1.f : (c12 == 1 ? 0.5f : 0.f);
+    s[0] = s1 * sm;
+    s[1] = (1.f - s1) * sm;
+}
+
+__global__ void k_erode_bwd(const uint16_t *__restrict__ code, const float *__restrict__ dy, float *__restrict__ dx,
+                            long total, int D, int H, int W) {
+    const long HW = (long)H * W, DHW = (long)D * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i % DHW;
+        int pos[3] = {(int)(r / HW), (int)((r % HW) / W), (int)(r % W)};
+        const int len[3] = {D, H, W};
+        const long st[3] = {HW, (long)W, 1};
+        float g = 0.f;
+        // fixed accumulation order: centre, then axis D (-,+), H (-,+), W (-,+)
+        {
+            uint16_t c = code[i];
+            float s[3];
+            erode_shares(c, s);
+            float gy = dy[i];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+                if (((c >> (2 * a)) & 3) == 1) g += s[a] * gy;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+            for (int o = -1; o <= 1; o += 2) {
+                int q = pos[a] + o;  // output voxel at offset o along axis a; this voxel sits at -o in its window
+                if (q < 0 || q >= len[a]) continue;
+                long j = i + (long)o * st[a];
+                uint16_t c = code[j];
+                if ((int)((c >> (2 * a)) & 3) == (1 - o)) {
+                    float s[3];
+                    erode_shares(c, s);
+                    g += s[a] * dy[j];
+                }
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dilate (3x3x3 max)
+__global__ void k_dilate_fwd(const float *__restrict__ x, float *__restrict__ y, uint8_t *__restrict__ code, long total,
+                             int D, int H, int W) {
+    const long HW = (long)H * W, DHW = (long)D * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i % DHW;
+        int d = (int)(r / HW), h = (int)((r % HW) / W), w = (int)(r % W);
+        float best = -INFINITY;
+        int arg = 13;
+        bool have = false;
+        for (int a = -1; a <= 1; a++) {
+            if (d + a < 0 || d + a >= D) continue;
+            for (int b = -1; b <= 1; b++) {
+                if (h + b < 0 || h + b >= H) continue;
+#pragma unroll
+                for (int c = -1; c <= 1; c++) {
+                    if (w + c < 0 || w + c >= W) continue;
+                    float v = x[i + a * HW + b * W + c];
+                    if (!have || v > best) {  // first maximum in scan order (max_pool3d CPU kernel)
+                        best = v;
+                        arg = (a + 1) * 9 + (b + 1) * 3 + (c + 1);
+                        have = true;
+                    }
+                }
+            }
+        }
+        y[i] = best;
+        if (code) code[i] = (uint8_t)arg;
+    }
+}
+
+__global__ void k_dilate_bwd(const uint8_t *__restrict__ code, const float *__restrict__ dy, float *__restrict__ dx,
+                             long total, int D, int H, int W) {
+    const long HW = (long)H * W, DHW = (long)D * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i % DHW;
+        int d = (int)(r / HW), h = (int)((r % HW) / W), w = (int)(r % W);
+        float g = 0.f;
+        for (int a = -1; a <= 1; a++) {
+            if (d + a < 0 || d + a >= D) continue;
+            for (int b = -1; b <= 1; b++) {
+                if (h + b < 0 || h + b >= H) continue;
+#pragma unroll
+                for (int c = -1; c <= 1; c++) {
+                    if (w + c < 0 || w + c >= W) continue;
+                    long j = i + a * HW + b * W + c;  // output voxel; this voxel is at (-a,-b,-c) in its window
+                    int want = (1 - a) * 9 + (1 - b) * 3 + (1 - c);
+                    if ((int)code[j] == want) g += dy[j];
+                }
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ skeleton update
+__global__ void k_skel_update_fwd(const float *__restrict__ img, const float *__restrict__ opened,
+                                  const float *__restrict__ skel_in, float *__restrict__ skel_out, long n, int init) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float delta = fmaxf(img[i] - opened[i], 0.f);
+        if (init) {
+            skel_out[i] = delta;
+        } else {
+            float s = skel_in[i];
+            float prod = s * delta;
+            skel_out[i] = s + fmaxf(delta - prod, 0.f);
+        }
+    }
+}
+
+__global__ void k_skel_update_bwd(const float *__restrict__ img, const float *__restrict__ opened,
+                                  const float *__restrict__ skel_in, const float *__restrict__ go,
+                                  float *__restrict__ d_img, float *__restrict__ d_opened, float *__restrict__ d_skel,
+                                  long n, int init) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float diff = img[i] - opened[i];
+        float delta = fmaxf(diff, 0.f);
+        float g = go[i];
+        float gdelta;
+        if (init) {
+            gdelta = g;
+        } else {
+            float s = skel_in[i];
+            float prod = s * delta;
+            float r = delta - prod;
+            float gr = r > 0.f ? g : 0.f;     // relu'(r)
+            gdelta = gr - gr * s;            // d r/d delta = 1 - s  (autograd: gr + (-gr)*s)
+            d_skel[i] = g + (-gr) * delta;   // d/dskel of skel + relu(delta - skel*delta)
+        }
+        float gi = diff > 0.f ? gdelta : 0.f;
+        d_img[i] = gi;
+        d_opened[i] = -gi;
+    }
+}
+
+__global__ void k_dot_sum(const float *__restrict__ a, const float *__restrict__ b, double *__restrict__ partial,
+                          long n) {
+    __shared__ double red[2 * 16];
+    double acc[2] = {0.0, 0.0};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float x = a[i];
+        acc[0] += (double)x * (double)b[i];
+        acc[1] += (double)x;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        partial[(size_t)blockIdx.x * 2 + 0] = acc[0];
+        partial[(size_t)blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
+__global__ void k_cldice_combine(const float *__restrict__ s, float *__restrict__ out, float smooth) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float d1 = s[1] + smooth, d3 = s[3] + smooth;
+    float a = (s[0] + smooth) / d1, b = (s[2] + smooth) / d3;
+    float ab = a + b;
+    out[0] = 1.0f - 2.0f * (a * b) / ab;
+    float dfa = 2.0f * b * b / (ab * ab), dfb = 2.0f * a * a / (ab * ab);
+    out[1] = -dfa / d1;
+    out[2] = dfa * a / d1;
+    out[3] = -dfb / d3;
+    out[4] = dfb * b / d3;
+}
+
+// ------------------------------------------------------------------------------------------------ connected components
+__global__ void k_threshold(const float *__restrict__ f, uint8_t *__restrict__ m, long n, float thr, int ge) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        m[i] = ge ? (f[i] >= thr) : (f[i] > thr);
+}
+
+__global__ void k_cc_init(const uint8_t *__restrict__ mask, int32_t *__restrict__ parent, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        parent[i] = mask[i] ? (int32_t)i : -1;
+}
+
+__device__ inline int32_t cc_find(int32_t *parent, int32_t x) {
+    // parent[] only ever decreases (atomicMin), so the walk terminates at a root
+    int32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+
+__device__ inline void cc_union(int32_t *parent, int32_t a, int32_t b) {
+    // link the larger root under the smaller one; retry when another wave re-rooted `a` meanwhile
+    for (int guard = 0; guard < (1 << 30); guard++) {
+        a = cc_find(parent, a);
+        b = cc_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            int32_t t = a;
+            a = b;
+            b = t;
+        }
+        int32_t old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;  // a was no longer a root: continue from what it pointed to
+    }
+}
+
+struct CcOffsets {
+    int n;
+    int off[13][3];
+};
+
+__global__ void k_cc_merge(const uint8_t *__restrict__ mask, int32_t *__restrict__ parent, int D, int H, int W,
+                           CcOffsets offs) {
+    const long HW = (long)H * W, total = (long)D * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (!mask[i]) continue;
+        int d = (int)(i / HW), h = (int)((i % HW) / W), w = (int)(i % W);
+        for (int k = 0; k < offs.n; k++) {
+            int dd = d + offs.off[k][0], hh = h + offs.off[k][1], ww = w + offs.off[k][2];
+            if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            long j = ((long)dd * H + hh) * W + ww;
+            if (mask[j]) cc_union(parent, (int32_t)i, (int32_t)j);
+        }
+    }
+}
+
+__global__ void k_cc_flatten(int32_t *__restrict__ parent, int32_t *__restrict__ count, long n) {
+    // every root is final after k_cc_merge completed (kernel boundary); labels = 1 + root index
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int32_t p = parent[i];
+        if (p < 0) continue;
+        if (p == (int32_t)i) atomicAdd(count, 1);
+    }
+}
+// in-place path compression: non-roots are rewritten to their root index, which is still a valid ancestor for any
+// concurrent reader; roots (parent[r] == r) are never rewritten.
+__global__ void k_cc_compress(int32_t *parent, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int32_t p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p < 0) continue;
+        int32_t x = (int32_t)i;
+        while (p != x) {
+            x = p;
+            p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&parent[i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// after the kernel boundary every entry holds its root (or -1): label = root + 1, background 0
+__global__ void k_cc_finish(int32_t *labels, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        labels[i] = labels[i] + 1;
+}
+
+}  // namespace mvd
+
+using namespace mvd;
+
+static inline long ew_grid(long n) {
+    long b = cdiv(n, 256);
+    return b > 4096 ? 4096 : (b < 1 ? 1 : b);
+}
+
+static int fill_offsets(int conn, CcOffsets *o) {
+    o->n = 0;
+    if (conn == 6) {
+        int t[3][3] = {{0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
+        for (int i = 0; i < 3; i++) memcpy(o->off[o->n++], t[i], sizeof(int) * 3);
+    } else if (conn == 14) {
+        int t[7][3] = {{0, 0, 1}, {0, 1, 0}, {1, 0, 0}, {0, 1, 1}, {1, 0, 1}, {1, 1, 0}, {1, 1, 1}};
+        for (int i = 0; i < 7; i++) memcpy(o->off[o->n++], t[i], sizeof(int) * 3);
+    } else if (conn == 26) {
+        for (int dz = 0; dz <= 1; dz++)
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (dz == 0 && (dy < 0 || (dy == 0 && dx <= 0))) continue;
+                    o->off[o->n][0] = dz;
+                    o->off[o->n][1] = dy;
+                    o->off[o->n][2] = dx;
+                    o->n++;
+                }
+    } else {
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" {
+
+#define VOL_CHECK(name)                                                                                        \
+    MVD_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && (long)NC * D * H * W < (1L << 40), name ": bad volume shape")
+
+int mvd_soft_erode_fwd(const float *x, float *y, uint16_t *code, int NC, int D, int H, int W, void *stream) {
+    MVD_REQUIRE(x && y, "soft_erode_fwd: null pointer");
+    VOL_CHECK("soft_erode_fwd");
+    long total = (long)NC * D * H * W;
+    hipLaunchKernelGGL(k_erode_fwd, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), x, y, code, total, D, H, W);
+    return check_launch("soft_erode_fwd");
+}
+int mvd_soft_erode_bwd(const uint16_t *code, const float *dy, float *dx, int NC, int D, int H, int W, void *stream) {
+    MVD_REQUIRE(code && dy && dx, "soft_erode_bwd: null pointer");
+    VOL_CHECK("soft_erode_bwd");
+    long total = (long)NC * D * H * W;
+    hipLaunchKernelGGL(k_erode_bwd, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), code, dy, dx, total, D, H, W);
+    return check_launch("soft_erode_bwd");
+}
+int mvd_soft_dilate_fwd(const float *x, float *y, uint8_t *code, int NC, int D, int H, int W, void *stream) {
+    MVD_REQUIRE(x && y, "soft_dilate_fwd: null pointer");
+    VOL_CHECK("soft_dilate_fwd");
+    long total = (long)NC * D * H * W;
+    hipLaunchKernelGGL(k_dilate_fwd, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), x, y, code, total, D, H, W);
+    return check_launch("soft_dilate_fwd");
+}
+int mvd_soft_dilate_bwd(const uint8_t *code, const float *dy, float *dx, int NC, int D, int H, int W, void *stream) {
+    MVD_REQUIRE(code && dy && dx, "soft_dilate_bwd: null pointer");
+    VOL_CHECK("soft_dilate_bwd");
+    long total = (long)NC * D * H * W;
+    hipLaunchKernelGGL(k_dilate_bwd, dim3(ew_grid(total)), dim3(256), 0, as_stream(stream), code, dy, dx, total, D, H,
+                       W);
+    return check_launch("soft_dilate_bwd");
+}
+
+int mvd_skel_update_fwd(const float *img, const float *opened, const float *skel_in, float *skel_out, long n, int init,
+                        void *stream) {
+    MVD_REQUIRE(img && opened && skel_out && (init || skel_in) && n > 0, "skel_update_fwd: bad arguments");
+    hipLaunchKernelGGL(k_skel_update_fwd, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), img, opened, skel_in,
+                       skel_out, n, init);
+    return check_launch("skel_update_fwd");
+}
+int mvd_skel_update_bwd(const float *img, const float *opened, const float *skel_in, const float *d_skel_out,
+                        float *d_img, float *d_opened, float *d_skel_in, long n, int init, void *stream) {
+    MVD_REQUIRE(img && opened && d_skel_out && d_img && d_opened && (init || (skel_in && d_skel_in)) && n > 0,
+                "skel_update_bwd: bad arguments");
+    hipLaunchKernelGGL(k_skel_update_bwd, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), img, opened, skel_in,
+                       d_skel_out, d_img, d_opened, d_skel_in, n, init);
+    return check_launch("skel_update_bwd");
+}
+
+size_t mvd_dot_sum_workspace_bytes(long n) {
+    long b = cdiv(n, 256);
+    if (b > 1024) b = 1024;
+    return (size_t)b * 2 * sizeof(double) + 256;
+}
+int mvd_dot_sum(const float *a, const float *b, float *out, long n, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(a && b && out && ws && n > 0, "dot_sum: bad arguments");
+    MVD_REQUIRE(ws_bytes >= mvd_dot_sum_workspace_bytes(n), "dot_sum: workspace too small");
+    long bx = cdiv(n, 256);
+    if (bx > 1024) bx = 1024;
+    double *partial = reinterpret_cast<double *>(ws);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_dot_sum, dim3(bx), dim3(256), 0, s, a, b, partial, n);
+    if (check_launch("dot_sum")) return 1;
+    return reduce_partials(partial, out, (int)bx, 2, s);
+}
+
+int mvd_cldice_combine(const float *sums, float *out, float smooth, void *stream) {
+    MVD_REQUIRE(sums && out, "cldice_combine: null pointer");
+    hipLaunchKernelGGL(k_cldice_combine, dim3(1), dim3(64), 0, as_stream(stream), sums, out, smooth);
+    return check_launch("cldice_combine");
+}
+
+int mvd_threshold_mask(const float *f, uint8_t *mask, long n, float thr, int ge, void *stream) {
+    MVD_REQUIRE(f && mask && n > 0, "threshold_mask: bad arguments");
+    hipLaunchKernelGGL(k_threshold, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), f, mask, n, thr, ge);
+    return check_launch("threshold_mask");
+}
+
+int mvd_cc_label(const uint8_t *mask, int32_t *labels, int32_t *count, int D, int H, int W, int conn, void *stream) {
+    MVD_REQUIRE(mask && labels && count, "cc_label: null pointer");
+    MVD_REQUIRE(D > 0 && H > 0 && W > 0 && (long)D * H * W < 2147483647L, "cc_label: bad grid (int32 labels)");
+    CcOffsets offs;
+    MVD_REQUIRE(fill_offsets(conn, &offs) == 0, "cc_label: conn must be 6, 14 or 26");
+    long n = (long)D * H * W;
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(count, 0, sizeof(int32_t), s) != hipSuccess) {
+        set_error("cc_label: memset failed");
+        return 1;
+    }
+    // `labels` doubles as the parent forest until the last two passes
+    hipLaunchKernelGGL(k_cc_init, dim3(ew_grid(n)), dim3(256), 0, s, mask, labels, n);
+    hipLaunchKernelGGL(k_cc_merge, dim3(ew_grid(n)), dim3(256), 0, s, mask, labels, D, H, W, offs);
+    hipLaunchKernelGGL(k_cc_flatten, dim3(ew_grid(n)), dim3(256), 0, s, labels, count, n);
+    if (check_launch("cc_label merge")) return 1;
+    hipLaunchKernelGGL(k_cc_compress, dim3(ew_grid(n)), dim3(256), 0, s, labels, n);
+    hipLaunchKernelGGL(k_cc_finish, dim3(ew_grid(n)), dim3(256), 0, s, labels, n);
+    return check_launch("cc_label relabel");
+}
+}

@@ -1,0 +1,302 @@
+"""MI355X-native PlainConvUNet behind the reference's network_architecture plugin surface.
+
+Mirrors (names, constructor arguments, attributes, state_dict keys -- SURVEY.md App. C) the classes the reference
+instantiates through nnUNet/nnunetv2/utilities/get_network_from_plans.py:70-83 (`PlainConvUNet` of the un-vendored
+`dynamic_network_architectures`) and its fork-local decoder nnUNet/nnunetv2/training/my_network/UNetDecoder.py:13-121.
+Every tensor operation is a hand-written HIP kernel reached through the C ABI (ops.py); the modules subclass the
+torch.nn layer types only so that parameter registration, `state_dict()` keys, `InitWeights_He`
+(network_initialization.py:4-12, which dispatches on isinstance(nn.Conv3d / nn.ConvTranspose3d)) and DDP-style
+parameter handling behave exactly like the reference's modules.
+"""
+from typing import List, Sequence, Tuple, Type, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _tup3(v):
+    if isinstance(v, (int, np.integer)):
+        return (int(v),) * 3
+    return tuple(int(i) for i in v)
+
+
+class HipConv3d(nn.Conv3d):
+    """nn.Conv3d whose forward is mvd_conv3d_fwd (NDHWC, fp32 MFMA implicit GEMM).  `x2` (optional) is a second
+    input concatenated along channels without materialising the cat."""
+
+    def forward(self, x, x2=None):
+        return ops.Conv3dFn.apply(x, x2, self.weight, self.bias, self.stride)
+
+
+class HipConvTranspose3d(nn.ConvTranspose3d):
+    def forward(self, x):
+        return ops.ConvTranspose3dFn.apply(x, self.weight, self.bias, self.stride)
+
+
+class HipInstanceNorm3d(nn.InstanceNorm3d):
+    """Stand-alone InstanceNorm3d is never used on the path; inside ConvDropoutNormReLU it is fused with the
+    LeakyReLU (mvd_instnorm_lrelu_fwd).  Calling it alone applies slope 1 (identity activation)."""
+
+    def forward(self, x):
+        return ops.InstanceNormLeakyReLUFn.apply(x, self.weight, self.bias, self.eps, 1.0)
+
+
+class HipSegLayer(nn.Conv3d):
+    """1x1x1 Conv3d producing planar logits (decoder.seg_layers[s])."""
+
+    def forward(self, x):
+        return ops.SegHeadFn.apply(x, self.weight, self.bias)
+
+
+class ConvDropoutNormReLU(nn.Module):
+    """conv -> (no dropout) -> InstanceNorm3d -> LeakyReLU; kwargs as in get_network_from_plans.py:39-45."""
+
+    def __init__(self, conv_op, input_channels, output_channels, kernel_size, stride, conv_bias=False, norm_op=None,
+                 norm_op_kwargs=None, dropout_op=None, dropout_op_kwargs=None, nonlin=None, nonlin_kwargs=None,
+                 nonlin_first=False):
+        super().__init__()
+        if dropout_op is not None:
+            raise NotImplementedError("dropout is not on the reference's path (get_network_from_plans.py:43)")
+        if nonlin_first:
+            raise NotImplementedError("nonlin_first=False on the reference's path")
+        self.input_channels, self.output_channels = input_channels, output_channels
+        self.stride = _tup3(stride)
+        k = _tup3(kernel_size)
+        self.conv = HipConv3d(input_channels, output_channels, k, self.stride, padding=[(i - 1) // 2 for i in k],
+                              dilation=1, bias=conv_bias)
+        norm_op_kwargs = norm_op_kwargs or {'eps': 1e-5, 'affine': True}
+        self.norm = HipInstanceNorm3d(output_channels, **norm_op_kwargs)
+        nonlin_kwargs = dict(nonlin_kwargs or {'inplace': True})
+        self.nonlin = (nonlin or nn.LeakyReLU)(**nonlin_kwargs)
+        self.all_modules = nn.Sequential(self.conv, self.norm, self.nonlin)
+
+    def forward(self, x, x2=None):
+        y = self.conv(x, x2)
+        slope = getattr(self.nonlin, 'negative_slope', 0.01)
+        return ops.InstanceNormLeakyReLUFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, slope)
+
+    def compute_conv_feature_map_size(self, input_size):
+        output_size = [i // j for i, j in zip(input_size, self.stride)]
+        return np.prod([self.output_channels, *output_size], dtype=np.int64)
+
+
+class StackedConvBlocks(nn.Module):
+    def __init__(self, num_convs, conv_op, input_channels, output_channels, kernel_size, initial_stride,
+                 conv_bias=False, norm_op=None, norm_op_kwargs=None, dropout_op=None, dropout_op_kwargs=None,
+                 nonlin=None, nonlin_kwargs=None, nonlin_first=False):
+        super().__init__()
+        if not isinstance(output_channels, (tuple, list)):
+            output_channels = [output_channels] * num_convs
+        self.convs = nn.Sequential(
+            ConvDropoutNormReLU(conv_op, input_channels, output_channels[0], kernel_size, initial_stride, conv_bias,
+                                norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs,
+                                nonlin_first),
+            *[ConvDropoutNormReLU(conv_op, output_channels[i - 1], output_channels[i], kernel_size, 1, conv_bias,
+                                  norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs,
+                                  nonlin_first) for i in range(1, num_convs)])
+        self.output_channels = output_channels[-1]
+        self.initial_stride = _tup3(initial_stride)
+
+    def forward(self, x, x2=None):
+        for i, blk in enumerate(self.convs):
+            x = blk(x, x2) if i == 0 else blk(x)
+        return x
+
+    def compute_conv_feature_map_size(self, input_size):
+        output = self.convs[0].compute_conv_feature_map_size(input_size)
+        size_after_stride = [i // j for i, j in zip(input_size, self.initial_stride)]
+        for b in self.convs[1:]:
+            output += b.compute_conv_feature_map_size(size_after_stride)
+        return output
+
+
+class PlainConvEncoder(nn.Module):
+    def __init__(self, input_channels: int, n_stages: int, features_per_stage: Union[int, Sequence[int]],
+                 conv_op: Type = nn.Conv3d, kernel_sizes=3, strides=1, n_conv_per_stage: Union[int, Sequence[int]] = 2,
+                 conv_bias: bool = False, norm_op=None, norm_op_kwargs=None, dropout_op=None, dropout_op_kwargs=None,
+                 nonlin=None, nonlin_kwargs=None, return_skips: bool = False, nonlin_first: bool = False,
+                 pool: str = 'conv'):
+        super().__init__()
+        if conv_op is not nn.Conv3d:
+            raise NotImplementedError("3d_fullres path only (conv_op = nn.Conv3d)")
+        if pool != 'conv':
+            raise NotImplementedError("the reference's plans use strided convolutions (pool='conv')")
+        if isinstance(kernel_sizes, int):
+            kernel_sizes = [kernel_sizes] * n_stages
+        if isinstance(features_per_stage, int):
+            features_per_stage = [features_per_stage] * n_stages
+        if isinstance(n_conv_per_stage, int):
+            n_conv_per_stage = [n_conv_per_stage] * n_stages
+        if isinstance(strides, int):
+            strides = [strides] * n_stages
+        assert len(kernel_sizes) == n_stages and len(n_conv_per_stage) == n_stages
+        assert len(features_per_stage) == n_stages and len(strides) == n_stages
+        stages = []
+        for s in range(n_stages):
+            stages.append(nn.Sequential(StackedConvBlocks(
+                n_conv_per_stage[s], conv_op, input_channels, features_per_stage[s], kernel_sizes[s], strides[s],
+                conv_bias, norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs, nonlin_first)))
+            input_channels = features_per_stage[s]
+        self.stages = nn.Sequential(*stages)
+        self.output_channels = list(features_per_stage)
+        self.strides = [_tup3(i) for i in strides]
+        self.return_skips = return_skips
+        # read by the decoder (UNetDecoder.py:39-65)
+        self.conv_op, self.norm_op, self.norm_op_kwargs = conv_op, norm_op, norm_op_kwargs
+        self.nonlin, self.nonlin_kwargs = nonlin, nonlin_kwargs
+        self.dropout_op, self.dropout_op_kwargs = dropout_op, dropout_op_kwargs
+        self.conv_bias, self.kernel_sizes = conv_bias, [_tup3(k) for k in kernel_sizes]
+
+    def forward(self, x):
+        ret = []
+        for s in self.stages:
+            x = s(x)
+            ret.append(x)
+        return ret if self.return_skips else ret[-1]
+
+    def compute_conv_feature_map_size(self, input_size):
+        output = np.int64(0)
+        for s in range(len(self.stages)):
+            output += self.stages[s][-1].compute_conv_feature_map_size(input_size)
+            input_size = [i // j for i, j in zip(input_size, self.strides[s])]
+        return output
+
+
+class UNetDecoder(nn.Module):
+    """UNetDecoder.py:13-121 (without the fork's bottleneck attention insert :75-81,:91-102): per stage
+    transpconv -> [cat] -> stacked convs -> 1x1x1 seg layer; outputs high-res first."""
+
+    def __init__(self, encoder: PlainConvEncoder, num_classes: int,
+                 n_conv_per_stage: Union[int, Tuple[int, ...], List[int]], deep_supervision,
+                 nonlin_first: bool = False):
+        super().__init__()
+        self.deep_supervision = deep_supervision
+        self.encoder = encoder
+        self.num_classes = num_classes
+        n_stages_encoder = len(encoder.output_channels)
+        if isinstance(n_conv_per_stage, int):
+            n_conv_per_stage = [n_conv_per_stage] * (n_stages_encoder - 1)
+        assert len(n_conv_per_stage) == n_stages_encoder - 1
+        stages, transpconvs, seg_layers = [], [], []
+        for s in range(1, n_stages_encoder):
+            below = encoder.output_channels[-s]
+            skip = encoder.output_channels[-(s + 1)]
+            st = encoder.strides[-s]
+            transpconvs.append(HipConvTranspose3d(below, skip, st, st, bias=encoder.conv_bias))
+            stages.append(StackedConvBlocks(
+                n_conv_per_stage[s - 1], encoder.conv_op, 2 * skip, skip, encoder.kernel_sizes[-(s + 1)], 1,
+                encoder.conv_bias, encoder.norm_op, encoder.norm_op_kwargs, encoder.dropout_op,
+                encoder.dropout_op_kwargs, encoder.nonlin, encoder.nonlin_kwargs, nonlin_first))
+            seg_layers.append(HipSegLayer(skip, num_classes, 1, 1, 0, bias=True))
+        self.stages = nn.ModuleList(stages)
+        self.transpconvs = nn.ModuleList(transpconvs)
+        self.seg_layers = nn.ModuleList(seg_layers)
+
+    def forward(self, skips, return_last_feature=False):
+        lres_input = skips[-1]
+        seg_outputs = []
+        for s in range(len(self.stages)):
+            x = self.transpconvs[s](lres_input)
+            # torch.cat((x, skip), 1) is never materialised: the first conv reads both pointers (UNetDecoder.py:107)
+            x = self.stages[s](x, skips[-(s + 2)])
+            if self.deep_supervision:
+                seg_outputs.append(self.seg_layers[s](x))
+            elif s == (len(self.stages) - 1):
+                seg_outputs.append(self.seg_layers[-1](x))
+            lres_input = x
+        seg_outputs = seg_outputs[::-1]
+        r = seg_outputs if self.deep_supervision else seg_outputs[0]
+        if return_last_feature:
+            return r, lres_input
+        return r
+
+    def compute_conv_feature_map_size(self, input_size):
+        skip_sizes = []
+        for s in range(len(self.encoder.strides) - 1):
+            skip_sizes.append([i // j for i, j in zip(input_size, self.encoder.strides[s])])
+            input_size = skip_sizes[-1]
+        output = np.int64(0)
+        for s in range(len(self.stages)):
+            output += self.stages[s].compute_conv_feature_map_size(skip_sizes[-(s + 1)])
+            output += np.prod([self.encoder.output_channels[-(s + 2)], *skip_sizes[-(s + 1)]], dtype=np.int64)
+            if self.deep_supervision or (s == (len(self.stages) - 1)):
+                output += np.prod([self.num_classes, *skip_sizes[-(s + 1)]], dtype=np.int64)
+        return output
+
+
+class MI355PlainConvUNet(nn.Module):
+    """Drop-in for dynamic_network_architectures.architectures.unet.PlainConvUNet (same constructor signature)."""
+
+    def __init__(self, input_channels: int, n_stages: int, features_per_stage: Union[int, Sequence[int]],
+                 conv_op: Type = nn.Conv3d, kernel_sizes=3, strides=1, n_conv_per_stage: Union[int, Sequence[int]] = 2,
+                 num_classes: int = 2, n_conv_per_stage_decoder: Union[int, Sequence[int]] = 2, conv_bias: bool = False,
+                 norm_op=None, norm_op_kwargs=None, dropout_op=None, dropout_op_kwargs=None, nonlin=None,
+                 nonlin_kwargs=None, deep_supervision: bool = False, nonlin_first: bool = False):
+        super().__init__()
+        if isinstance(n_conv_per_stage, int):
+            n_conv_per_stage = [n_conv_per_stage] * n_stages
+        if isinstance(n_conv_per_stage_decoder, int):
+            n_conv_per_stage_decoder = [n_conv_per_stage_decoder] * (n_stages - 1)
+        assert len(n_conv_per_stage) == n_stages
+        assert len(n_conv_per_stage_decoder) == (n_stages - 1)
+        self.encoder = PlainConvEncoder(input_channels, n_stages, features_per_stage, conv_op, kernel_sizes, strides,
+                                        n_conv_per_stage, conv_bias, norm_op, norm_op_kwargs, dropout_op,
+                                        dropout_op_kwargs, nonlin, nonlin_kwargs, return_skips=True,
+                                        nonlin_first=nonlin_first)
+        self.decoder = UNetDecoder(self.encoder, num_classes, n_conv_per_stage_decoder, deep_supervision,
+                                   nonlin_first=nonlin_first)
+
+    def forward(self, x, return_last_feature=False):
+        if not x.is_cuda:
+            raise RuntimeError("MI355PlainConvUNet runs on the MI355X only (no CPU path); move the input to cuda")
+        skips = self.encoder(ops.to_ndhwc(x))
+        return self.decoder(skips, return_last_feature)
+
+    def compute_conv_feature_map_size(self, input_size):
+        return self.encoder.compute_conv_feature_map_size(input_size) + \
+            self.decoder.compute_conv_feature_map_size(input_size)
+
+
+PlainConvUNet = MI355PlainConvUNet  # the name get_network_from_plans.py:35 maps 'PlainConvUNet' to
+
+
+class InitWeights_He(object):
+    """network_initialization.py:4-12 (host-side, runs on whatever device the module lives on)."""
+
+    def __init__(self, neg_slope=1e-2):
+        self.neg_slope = neg_slope
+
+    def __call__(self, module):
+        if isinstance(module, (nn.Conv3d, nn.Conv2d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
+            module.weight = nn.init.kaiming_normal_(module.weight, a=self.neg_slope)
+            if module.bias is not None:
+                module.bias = nn.init.constant_(module.bias, 0)
+
+
+class MVDDualBranchNet(nn.Module):
+    """Dual-branch contract of the mutual-distillation trainer (HybridNetwork.py:1544-1571, MVDTrainer.py:895):
+    forward -> (logits_list_1, logits_list_2, feat_1, feat_2); `do_ds` toggles deep supervision
+    (MVDTrainer.py:802-806); with DS off single tensors are returned.  Each branch is a MI355PlainConvUNet; the
+    feature map is the last decoder stage output (cf. UNetDecoder_return_last_fea, UNetDecoder.py:1012-1027)."""
+
+    def __init__(self, branch1: MI355PlainConvUNet, branch2: MI355PlainConvUNet):
+        super().__init__()
+        self.branch1, self.branch2 = branch1, branch2
+
+    @property
+    def do_ds(self):
+        return self.branch1.decoder.deep_supervision
+
+    @do_ds.setter
+    def do_ds(self, v):
+        self.branch1.decoder.deep_supervision = v
+        self.branch2.decoder.deep_supervision = v
+
+    def forward(self, x):
+        x = ops.to_ndhwc(x)
+        o1, f1 = self.branch1(x, True)
+        o2, f2 = self.branch2(x, True)
+        return o1, o2, f1, f2

@@ -1,0 +1,610 @@
+"""torch.autograd.Function wrappers over the C ABI (include/mvdseg_hip.h).
+
+PyTorch supplies device memory (caching allocator), the current HIP stream and the autograd tape; every
+arithmetic operation of the hot path runs in libmvdseg_hip.so.  Activations are 5-D tensors of logical shape
+[N,C,D,H,W] stored NDHWC (torch.channels_last_3d); logits / targets / volumes of the topology losses are planar.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import call, i3, query
+
+CL3D = torch.channels_last_3d
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("multimodal_mvd_seg_amd ops need tensors on the MI355X (cuda) device; "
+                               "there is no CPU fallback")
+        if t is not None and t.dtype != torch.float32 and t.dtype not in (torch.uint8, torch.int32, torch.int64,
+                                                                          torch.int16):
+            raise RuntimeError(f"unsupported dtype {t.dtype} (this round's kernels compute in fp32)")
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device; kernels of one stream run in order so sharing it is safe."""
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes, device):
+        key = (device.index, torch.cuda.current_stream().cuda_stream)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
+def _is_cl3d(t):
+    return t.dim() == 5 and t.is_contiguous(memory_format=CL3D)
+
+
+def empty_cl3d(shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=CL3D)
+
+
+def to_ndhwc(t):
+    """[N,C,D,H,W] in any layout -> physical NDHWC (HIP transpose kernel when the tensor is planar)."""
+    _require_cuda(t)
+    if _is_cl3d(t):
+        return t
+    if not t.is_contiguous():
+        t = t.contiguous()
+    N, C = t.shape[:2]
+    V = t[0, 0].numel()
+    out = empty_cl3d(t.shape, t.device)
+    call("mvd_nchw_to_ndhwc", _p(t), _p(out), N, C, V, _stream())
+    return out
+
+
+def to_planar(t):
+    """physical NDHWC -> contiguous NCDHW."""
+    _require_cuda(t)
+    if t.is_contiguous():
+        return t
+    if not _is_cl3d(t):
+        return t.contiguous()
+    N, C = t.shape[:2]
+    V = t[0, 0].numel()
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    call("mvd_ndhwc_to_nchw", _p(t), _p(out), N, C, V, _stream())
+    return out
+
+
+def pack_weight(weight, transposed):
+    """torch Conv3d [K,C,kd,kh,kw] / ConvTranspose3d [C,K,kd,kh,kw] -> (wf [T,C,K], wb [T,K,C])."""
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    if transposed:
+        C, K = w.shape[:2]
+    else:
+        K, C = w.shape[:2]
+    T = w[0, 0].numel()
+    wf = torch.empty((T, C, K), dtype=torch.float32, device=w.device)
+    wb = torch.empty((T, K, C), dtype=torch.float32, device=w.device)
+    call("mvd_pack_weight", _p(w), _p(wf), _p(wb), K, C, T, 1 if transposed else 0, _stream())
+    return wf, wb
+
+
+def _out_dim(i, k, s):
+    return (i + 2 * ((k - 1) // 2) - k) // s + 1
+
+
+# ======================================================================================================== conv
+class Conv3dFn(Function):
+    """Conv3d(k in {1,3}, pad=(k-1)/2, stride in {1,2}) over the channel concat of x1 and (optional) x2.
+    Replaces nn.Conv3d of ConvDropoutNormReLU and torch.cat((x, skip), 1) (UNetDecoder.py:107)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, stride):
+        _require_cuda(x1, x2, weight, bias)
+        x1 = to_ndhwc(x1)
+        x2 = to_ndhwc(x2) if x2 is not None else None
+        K, C = weight.shape[:2]
+        ks = tuple(weight.shape[2:])
+        N, C1, D, H, W = x1.shape
+        C2 = x2.shape[1] if x2 is not None else 0
+        if C1 + C2 != C:
+            raise RuntimeError(f"conv3d: weight expects {C} input channels, got {C1}+{C2}")
+        if x2 is not None and tuple(x2.shape[2:]) != (D, H, W):
+            raise RuntimeError("conv3d: the two concatenated inputs differ in spatial size")
+        wf, wb = pack_weight(weight, False)
+        od = [_out_dim(i, k, s) for i, k, s in zip((D, H, W), ks, stride)]
+        y = empty_cl3d((N, K, *od), x1.device)
+        call("mvd_conv3d_fwd", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
+             _stream())
+        ctx.save_for_backward(x1, x2, wb)
+        ctx.geom = (N, C1, C2, D, H, W, K, ks, tuple(stride), tuple(od), bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x1, x2, wb = ctx.saved_tensors
+        N, C1, C2, D, H, W, K, ks, stride, od, has_bias = ctx.geom
+        dy = to_ndhwc(dy)
+        dev = dy.device
+        dx1 = dx2 = dw = db = None
+        need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
+        if need1 or need2:
+            dx1 = empty_cl3d((N, C1, D, H, W), dev)
+            dx2 = empty_cl3d((N, C2, D, H, W), dev) if x2 is not None else None
+            call("mvd_conv3d_dgrad", _p(dy), _p(wb), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks), i3(stride),
+                 _stream())
+        if ctx.needs_input_grad[2]:
+            T = ks[0] * ks[1] * ks[2]
+            dw = torch.empty((K, C1 + C2, *ks), dtype=torch.float32, device=dev)
+            db = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
+            nb = query("mvd_conv3d_wgrad_workspace_bytes", C1 + C2, K, T, N, *od)
+            ws = _Workspace.get(nb, dev)
+            call("mvd_conv3d_wgrad", _p(x1), C1, _p(x2), C2, _p(dy), _p(dw), _p(db), N, D, H, W, K, i3(ks), i3(stride),
+                 _p(ws), ws.numel(), _stream())
+        return (dx1 if need1 else None), (dx2 if need2 else None), dw, db, None
+
+
+class ConvTranspose3dFn(Function):
+    """ConvTranspose3d with kernel == stride (UNetDecoder.py:56-59)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        _require_cuda(x, weight, bias)
+        x = to_ndhwc(x)
+        C, K = weight.shape[:2]
+        if tuple(weight.shape[2:]) != tuple(stride):
+            raise RuntimeError("convT3d: only kernel_size == stride is on the hot path")
+        N, Cx, D, H, W = x.shape
+        if Cx != C:
+            raise RuntimeError("convT3d: channel mismatch")
+        wf, wb = pack_weight(weight, True)
+        y = empty_cl3d((N, K, D * stride[0], H * stride[1], W * stride[2]), x.device)
+        call("mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _stream())
+        ctx.save_for_backward(x, wb)
+        ctx.geom = (N, C, K, D, H, W, tuple(stride), bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        N, C, K, D, H, W, stride, has_bias = ctx.geom
+        dy = to_ndhwc(dy)
+        dev = dy.device
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_cl3d((N, C, D, H, W), dev)
+            call("mvd_convT3d_dgrad", _p(dy), _p(wb), _p(dx), N, D, H, W, C, K, i3(stride), _stream())
+        if ctx.needs_input_grad[1]:
+            T = stride[0] * stride[1] * stride[2]
+            dw = torch.empty((C, K, *stride), dtype=torch.float32, device=dev)
+            db = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
+            nb = query("mvd_convT3d_wgrad_workspace_bytes", C, K, T, N, D, H, W)
+            ws = _Workspace.get(nb, dev)
+            call("mvd_convT3d_wgrad", _p(x), _p(dy), _p(dw), _p(db), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
+                 _stream())
+        return dx, dw, db, None
+
+
+# ======================================================================================================== norm
+class InstanceNormLeakyReLUFn(Function):
+    """InstanceNorm3d(eps, affine) + LeakyReLU(slope) fused (get_network_from_plans.py:41-44)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, slope):
+        _require_cuda(x, gamma, beta)
+        x = to_ndhwc(x)
+        N, C = x.shape[:2]
+        V = x[0, 0].numel()
+        y = empty_cl3d(x.shape, x.device)
+        mean = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        nb = query("mvd_instnorm_workspace_bytes", N, V, C)
+        ws = _Workspace.get(nb, x.device)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        call("mvd_instnorm_lrelu_fwd", _p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V, C, float(eps), float(slope),
+             _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(x, g, b, mean, rstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, g, b, mean, rstd = ctx.saved_tensors
+        dy = to_ndhwc(dy)
+        N, C = x.shape[:2]
+        V = x[0, 0].numel()
+        dx = empty_cl3d(x.shape, x.device)
+        dg = torch.empty((C,), dtype=torch.float32, device=x.device)
+        db = torch.empty((C,), dtype=torch.float32, device=x.device)
+        nb = query("mvd_instnorm_workspace_bytes", N, V, C)
+        ws = _Workspace.get(nb, x.device)
+        call("mvd_instnorm_lrelu_bwd", _p(x), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), N, V, C,
+             ctx.slope, _p(ws), ws.numel(), _stream())
+        return dx, dg, db, None, None
+
+
+# ======================================================================================================== seg head
+class SegHeadFn(Function):
+    """1x1x1 Conv3d C -> K producing planar logits [N,K,D,H,W] (UNetDecoder.py:70,110)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_cuda(x, weight, bias)
+        x = to_ndhwc(x)
+        N, C = x.shape[:2]
+        K = weight.shape[0]
+        V = x[0, 0].numel()
+        w = weight.detach().reshape(K, C).contiguous()
+        logits = torch.empty((N, K, *x.shape[2:]), dtype=torch.float32, device=x.device)
+        call("mvd_seghead_fwd", _p(x), _p(w), _p(bias), _p(logits), N, V, C, K, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.wshape = tuple(weight.shape)
+        return logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dl):
+        x, w = ctx.saved_tensors
+        N, C = x.shape[:2]
+        K = w.shape[0]
+        V = x[0, 0].numel()
+        dl = dl.contiguous()
+        dev = x.device
+        dx = empty_cl3d(x.shape, dev) if ctx.needs_input_grad[0] else None
+        dw = torch.empty((K, C), dtype=torch.float32, device=dev)
+        db = torch.empty((K,), dtype=torch.float32, device=dev)
+        nb = query("mvd_seghead_bwd_workspace_bytes", N, V, C, K)
+        ws = _Workspace.get(nb, dev)
+        call("mvd_seghead_bwd", _p(x), _p(w), _p(dl), _p(dx), _p(dw), _p(db), N, V, C, K, 0, _p(ws), ws.numel(), _stream())
+        return dx, dw.view(ctx.wshape), db
+
+
+# ======================================================================================================== losses
+def _flat_target(t, N, V):
+    """float label map [N,1,...] or [N,...] -> contiguous [N,V]."""
+    t = t.reshape(N, -1)
+    if t.shape[1] != V:
+        raise RuntimeError(f"target has {t.shape[1]} voxels per sample, logits have {V}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class DeepSupervisedDCCEFn(Function):
+    """sum_i w_i * (w_ce*CE(x_i,t_i) + w_dice*(-softDice(softmax(x_i),t_i))) in one autograd node
+    (DeepSupervisionWrapper o DC_and_CE_loss, nnUNetTrainer.py:359-374).  Levels with w_i == 0 contribute exact-zero
+    gradients (upstream 2.1.1 evaluates them; see oracle/loss_oracle.py).  `gather` (optional) maps the per-sample
+    stats [N,3K+1] to the all-gathered stats for DDP batch-dice (collective C2); it returns (stats_all, my_offset,
+    grad_multiplier)."""
+
+    @staticmethod
+    def forward(ctx, weights, cfg, gather, targets, *logits):
+        batch_dice, do_bg, smooth, w_ce, w_dice = cfg
+        dev = logits[0].device
+        total = torch.zeros((1,), dtype=torch.float32, device=dev)
+        saved = []
+        ctx.levels = []
+        for i, (x, t) in enumerate(zip(logits, targets)):
+            if weights[i] == 0:
+                ctx.levels.append(None)
+                continue
+            _require_cuda(x, t)
+            x = x.contiguous()
+            N, K = x.shape[:2]
+            V = x[0, 0].numel()
+            t = _flat_target(t, N, V)
+            stats = torch.empty((N, 3 * K + 1), dtype=torch.float32, device=dev)
+            nb = query("mvd_dcce_workspace_bytes", N, V, K)
+            ws = _Workspace.get(nb, dev)
+            call("mvd_dcce_fwd", _p(x), _p(t), _p(stats), N, V, K, _p(ws), ws.numel(), _stream())
+            dstats, off, mult = (stats, 0, 1.0)
+            if gather is not None and batch_dice:
+                dstats, off, mult = gather(stats)
+            Nd = dstats.shape[0]
+            loss = torch.empty((3,), dtype=torch.float32, device=dev)
+            coef = torch.empty((Nd, K, 2), dtype=torch.float32, device=dev)
+            call("mvd_dcce_finalize", _p(stats), N, _p(dstats), Nd, _p(loss), _p(coef), V, K, int(batch_dice), int(do_bg),
+                 float(smooth), float(w_ce), float(w_dice), _stream())
+            call("mvd_axpy", _p(total), _p(loss), float(weights[i]), 1, _stream())
+            saved += [x, t, coef[off:off + N].contiguous() if (off or Nd != N) else coef]
+            ctx.levels.append((N, K, V, float(weights[i]) , float(mult)))
+        ctx.save_for_backward(*saved)
+        ctx.w_ce = float(w_ce)
+        ctx.shapes = [tuple(x.shape) for x in logits]
+        return total.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        g = g.contiguous()
+        grads = []
+        j = 0
+        for lvl, shp in zip(ctx.levels, ctx.shapes):
+            if lvl is None:
+                grads.append(torch.zeros(shp, dtype=torch.float32, device=g.device))
+                continue
+            N, K, V, w, mult = lvl
+            x, t, coef = saved[j:j + 3]
+            j += 3
+            if mult != 1.0:
+                coef = coef * mult  # ddp batch-dice: AllGatherGrad.backward sums the (identical) grads of all ranks
+            dl = torch.empty(shp, dtype=torch.float32, device=g.device)
+            call("mvd_dcce_bwd", _p(x), _p(t), _p(coef), _p(g), w, _p(dl), N, V, K, ctx.w_ce, _stream())
+            grads.append(dl)
+        return (None, None, None, None, *grads)
+
+
+def argmax_counts(logits, target):
+    """validation_step online evaluation (nnUNetTrainer.py:973-990): returns int64 [K,3] = (tp, fp, fn) per class."""
+    _require_cuda(logits, target)
+    x = logits.contiguous()
+    N, K = x.shape[:2]
+    V = x[0, 0].numel()
+    t = _flat_target(target, N, V)
+    counts = torch.empty((K, 3), dtype=torch.int64, device=x.device)
+    call("mvd_argmax_counts", _p(x), _p(t), _p(counts), N, V, K, _stream())
+    return counts
+
+
+def _kl_strides(t):
+    """(N, C, V, sn, sc, sv) of a [N,C,*spatial] tensor whose spatial block is dense in either planar or NDHWC order."""
+    N, C = t.shape[:2]
+    V = t[0, 0].numel()
+    if t.is_contiguous():
+        return N, C, V, C * V, V, 1
+    if _is_cl3d(t):
+        return N, C, V, C * V, 1, C
+    # channel slice of a planar tensor ([N,1,...] view with batch stride K*V)
+    st = t.stride()
+    sp = t[0, 0]
+    if sp.is_contiguous():
+        return N, C, V, st[0], st[1], 1
+    raise RuntimeError("kl: unsupported memory layout")
+
+
+class DistillKLFn(Function):
+    """distill_kl / l2_loss(channel_wise=True) (other_loss.py:51-64, :67-76)."""
+
+    @staticmethod
+    def forward(ctx, ys, yt, T, eps_s, pad_zero_channel):
+        _require_cuda(ys, yt)
+        if ys.shape != yt.shape:
+            raise RuntimeError("kl: shape mismatch")
+        gs = _kl_strides(ys)
+        if _kl_strides(yt) != gs:
+            yt = yt.contiguous(memory_format=CL3D) if _is_cl3d(ys) else yt.contiguous()
+            ys = ys if _kl_strides(ys) == _kl_strides(yt) else ys.contiguous()
+            gs = _kl_strides(ys)
+            if _kl_strides(yt) != gs:
+                raise RuntimeError("kl: the two inputs must share a memory layout")
+        N, C, V, sn, sc, sv = gs
+        out = torch.empty((1,), dtype=torch.float32, device=ys.device)
+        nb = query("mvd_kl_workspace_bytes", N, V)
+        ws = _Workspace.get(nb, ys.device)
+        call("mvd_kl_fwd", _p(ys), _p(yt), _p(out), N, C, V, sn, sc, sv, float(T), float(eps_s), int(pad_zero_channel),
+             _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(ys, yt)
+        ctx.cfg = (gs, float(T), float(eps_s), int(pad_zero_channel))
+        return out.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        ys, yt = ctx.saved_tensors
+        (N, C, V, sn, sc, sv), T, eps_s, pad = ctx.cfg
+        g = g.contiguous()
+        # gradients are written with the inputs' strides into buffers of identical geometry
+        def like(t):
+            return torch.empty_strided(t.shape, t.stride(), dtype=torch.float32, device=t.device) \
+                if (t.is_contiguous() or _is_cl3d(t)) else None
+        gs = like(ys) if ctx.needs_input_grad[0] else None
+        gt = like(yt) if ctx.needs_input_grad[1] else None
+        dense = ys.is_contiguous() or _is_cl3d(ys)
+        if not dense:
+            # strided channel-slice view: write dense [N,C,V] grads (sn = C*V)
+            if ctx.needs_input_grad[0]:
+                gs = torch.empty(ys.shape, dtype=torch.float32, device=ys.device)
+            if ctx.needs_input_grad[1]:
+                gt = torch.empty(yt.shape, dtype=torch.float32, device=yt.device)
+            ysd, ytd = ys.contiguous(), yt.contiguous()
+            call("mvd_kl_bwd", _p(ysd), _p(ytd), _p(g), 1.0, _p(gs), _p(gt), N, C, V, C * V, V, 1, T, eps_s, pad, _stream())
+        else:
+            call("mvd_kl_bwd", _p(ys), _p(yt), _p(g), 1.0, _p(gs), _p(gt), N, C, V, sn, sc, sv, T, eps_s, pad, _stream())
+        return gs, gt, None, None, None
+
+
+class SoftmaxSelectFn(Function):
+    """softmax(logits, 1)[:, sel:sel+1] on planar logits."""
+
+    @staticmethod
+    def forward(ctx, logits, sel):
+        _require_cuda(logits)
+        x = logits.contiguous()
+        N, K = x.shape[:2]
+        V = x[0, 0].numel()
+        p = torch.empty((N, 1, *x.shape[2:]), dtype=torch.float32, device=x.device)
+        call("mvd_softmax_select_fwd", _p(x), _p(p), N, V, K, int(sel), _stream())
+        ctx.save_for_backward(x)
+        ctx.sel = int(sel)
+        return p
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, K = x.shape[:2]
+        V = x[0, 0].numel()
+        g = g.contiguous()
+        dl = torch.empty_like(x)
+        call("mvd_softmax_select_bwd", _p(x), _p(g), _p(dl), N, V, K, ctx.sel, _stream())
+        return dl, None
+
+
+def label_mask(labels, value):
+    _require_cuda(labels)
+    x = labels.contiguous().float()
+    out = torch.empty_like(x)
+    call("mvd_label_mask", _p(x), _p(out), x.numel(), float(value), _stream())
+    return out
+
+
+# ======================================================================================================== soft skeleton
+def _vol(t):
+    if t.dim() != 5:
+        raise RuntimeError("soft-skeleton ops take [N,C,D,H,W] volumes")
+    t = t.contiguous()
+    N, C, D, H, W = t.shape
+    return t, N * C, D, H, W
+
+
+class SoftErodeFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x, NC, D, H, W = _vol(x)
+        y = torch.empty_like(x)
+        code = torch.empty(x.shape, dtype=torch.int16, device=x.device) if x.requires_grad or True else None
+        call("mvd_soft_erode_fwd", _p(x), _p(y), _p(code), NC, D, H, W, _stream())
+        ctx.save_for_backward(code)
+        ctx.dims = (NC, D, H, W)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (code,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call("mvd_soft_erode_bwd", _p(code), _p(dy), _p(dx), *ctx.dims, _stream())
+        return dx
+
+
+class SoftDilateFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x, NC, D, H, W = _vol(x)
+        y = torch.empty_like(x)
+        code = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        call("mvd_soft_dilate_fwd", _p(x), _p(y), _p(code), NC, D, H, W, _stream())
+        ctx.save_for_backward(code)
+        ctx.dims = (NC, D, H, W)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (code,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        call("mvd_soft_dilate_bwd", _p(code), _p(dy), _p(dx), *ctx.dims, _stream())
+        return dx
+
+
+class SkelUpdateFn(Function):
+    """init: skel = relu(img - opened); else skel = skel + relu(delta - skel*delta) (soft_skeleton.py:31,35-36)."""
+
+    @staticmethod
+    def forward(ctx, img, opened, skel):
+        _require_cuda(img, opened, skel)
+        img, opened = img.contiguous(), opened.contiguous()
+        init = skel is None
+        if not init:
+            skel = skel.contiguous()
+        out = torch.empty_like(img)
+        call("mvd_skel_update_fwd", _p(img), _p(opened), _p(skel), _p(out), img.numel(), int(init), _stream())
+        ctx.save_for_backward(img, opened, skel)
+        ctx.init = init
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        img, opened, skel = ctx.saved_tensors
+        g = g.contiguous()
+        d_img, d_open = torch.empty_like(img), torch.empty_like(img)
+        d_skel = None if ctx.init else torch.empty_like(img)
+        call("mvd_skel_update_bwd", _p(img), _p(opened), _p(skel), _p(g), _p(d_img), _p(d_open), _p(d_skel), img.numel(),
+             int(ctx.init), _stream())
+        return d_img, d_open, d_skel
+
+
+class ClDiceFn(Function):
+    """1 - 2*tprec*tsens/(tprec+tsens) from (skel_pred, target, skel_true, pred) (clDice_metric.py:7-36 formula)."""
+
+    @staticmethod
+    def forward(ctx, skel_pred, target, skel_true, pred, smooth):
+        _require_cuda(skel_pred, target, skel_true, pred)
+        sp, tg, st, pr = (t.contiguous() for t in (skel_pred, target, skel_true, pred))
+        dev = sp.device
+        n = sp.numel()
+        sums = torch.empty((4,), dtype=torch.float32, device=dev)
+        nb = query("mvd_dot_sum_workspace_bytes", n)
+        ws = _Workspace.get(nb, dev)
+        call("mvd_dot_sum", _p(sp), _p(tg), _p(sums), n, _p(ws), ws.numel(), _stream())
+        call("mvd_dot_sum", _p(st), _p(pr), _p(sums[2:]), n, _p(ws), ws.numel(), _stream())
+        out = torch.empty((5,), dtype=torch.float32, device=dev)
+        call("mvd_cldice_combine", _p(sums), _p(out), float(smooth), _stream())
+        ctx.save_for_backward(tg, st, out)
+        return out[0].clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        tg, st, out = ctx.saved_tensors
+        # d/d skel_pred = g*(out1*target + out2); d/d pred = g*out3*skel_true  (tiny scalar glue on device)
+        c = out * g
+        d_sp = torch.addcmul(c[2].expand_as(tg), tg, c[1].expand_as(tg)) if ctx.needs_input_grad[0] else None
+        d_pr = st * c[3] if ctx.needs_input_grad[3] else None
+        return d_sp, None, None, d_pr, None
+
+
+# ======================================================================================================== topology (integer)
+def cc_label(mask, conn=6):
+    """Connected components of a [D,H,W] uint8/bool mask: (int32 labels, int32 count tensor).  Canonical labels
+    (1 + smallest linear index of the component) -> bit-exact against oracle/cc_oracle.c."""
+    _require_cuda(mask)
+    if mask.dim() != 3:
+        raise RuntimeError("cc_label takes a [D,H,W] mask")
+    m = mask.to(torch.uint8).contiguous()
+    D, H, W = m.shape
+    labels = torch.empty((D, H, W), dtype=torch.int32, device=m.device)
+    count = torch.empty((1,), dtype=torch.int32, device=m.device)
+    call("mvd_cc_label", _p(m), _p(labels), _p(count), D, H, W, int(conn), _stream())
+    return labels, count
+
+
+def threshold_mask(f, thr, ge=False):
+    _require_cuda(f)
+    x = f.contiguous()
+    m = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    call("mvd_threshold_mask", _p(x), _p(m), x.numel(), float(thr), int(ge), _stream())
+    return m
+
+
+def set_conv_engine(mode):
+    """'auto' (MFMA implicit GEMM when the shape allows) or 'scalar' (gather kernels only; cross-check)."""
+    call("mvd_set_conv_engine", {"auto": 0, "scalar": 1}[mode])
+
+
+def lib_available():
+    try:
+        _lib.load()
+        return True
+    except (RuntimeError, OSError, AttributeError):
+        return False

@@ -1,0 +1,391 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every HIP kernel, called through the C ABI
+(multimodal_mvd_seg_amd.ops -> ctypes -> libmvdseg_hip.so), against the golden fixtures of tests/golden/ and, for
+larger seeded inputs, against the CPU oracle (oracle/) evaluated on the box's host cores.
+
+Tolerances: fp32 results within 1e-4 abs of the oracle (north_star) -- most checks are tighter and say so;
+integer / min-max work (soft skeleton forward, connected components, argmax counts) must be bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, load_npz
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu_and_lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from multimodal_mvd_seg_amd import _lib
+    _lib.load()  # fails loudly if the HIP extension is missing
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // 2))
+
+
+def G(a, requires_grad=False):
+    t = torch.from_numpy(np.asarray(a)).to(DEV)
+    if requires_grad:
+        t.requires_grad_()
+    return t
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a, b = a.detach().float().cpu(), torch.as_tensor(np.asarray(b)).float()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"{what}: max abs err {float(err.max()):.3e} (tol {atol:g}+{rtol:g}*|ref|)"
+
+
+# ================================================================================================ conv
+CONV_FIXT = sorted(f for f in os.listdir(GOLDEN) if f.startswith("conv3d_"))
+
+
+@pytest.mark.parametrize("engine", ["auto", "scalar"])
+@pytest.mark.parametrize("name", CONV_FIXT)
+def test_conv3d_fwd_dgrad_wgrad(name, engine):
+    from multimodal_mvd_seg_amd import ops
+    z = load_npz(name)
+    ops.set_conv_engine(engine)
+    try:
+        x, w, b = G(z["x"], True), G(z["w"], True), G(z["b"], True)
+        y = ops.Conv3dFn.apply(x, None, w, b, tuple(int(i) for i in z["stride"]))
+        close(y, z["y"], 2e-5, 1e-5, "y")
+        y.backward(G(z["gy"]))
+        close(x.grad, z["gx"], 2e-5, 1e-5, "dx")
+        close(w.grad, z["gw"], 1e-4, 1e-5, "dw")
+        close(b.grad, z["gb"], 1e-4, 1e-5, "db")
+    finally:
+        ops.set_conv_engine("auto")
+
+
+def test_conv3d_two_pointer_concat_equals_cat():
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(2, 32, 6, 8, 10, generator=g)
+    b = torch.randn(2, 32, 6, 8, 10, generator=g)
+    w = torch.randn(32, 64, 3, 3, 3, generator=g) * 0.05
+    bias = torch.randn(32, generator=g) * 0.1
+    xa, xb = a.clone().requires_grad_(), b.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    ref = F.conv3d(torch.cat((xa, xb), 1), wr, bias, 1, 1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    ga, gb, gw = G(a, True), G(b, True), G(w, True)
+    y = ops.Conv3dFn.apply(ga, gb, gw, G(bias), (1, 1, 1))
+    y.backward(G(gy))
+    close(y, ref.detach(), 5e-5, 1e-5, "y")
+    close(ga.grad, xa.grad, 5e-5, 1e-5, "dx1")
+    close(gb.grad, xb.grad, 5e-5, 1e-5, "dx2")
+    close(gw.grad, wr.grad, 2e-4, 1e-5, "dw")
+
+
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.startswith("convT3d_")))
+def test_convT3d(name):
+    from multimodal_mvd_seg_amd import ops
+    z = load_npz(name)
+    x, w, b = G(z["x"], True), G(z["w"], True), G(z["b"], True)
+    y = ops.ConvTranspose3dFn.apply(x, w, b, tuple(int(i) for i in z["stride"]))
+    close(y, z["y"], 2e-5, 1e-5, "y")
+    y.backward(G(z["gy"]))
+    close(x.grad, z["gx"], 2e-5, 1e-5, "dx")
+    close(w.grad, z["gw"], 1e-4, 1e-5, "dw")
+    close(b.grad, z["gb"], 1e-4, 1e-5, "db")
+
+
+def test_seghead_conv1x1():
+    from multimodal_mvd_seg_amd import ops
+    z = load_npz("conv1x1.npz")
+    x, w, b = G(z["x"], True), G(z["w"], True), G(z["b"], True)
+    y = ops.SegHeadFn.apply(x, w, b)
+    assert y.is_contiguous()  # planar logits
+    close(y, z["y"], 1e-5, 1e-5, "y")
+    y.backward(G(z["gy"]))
+    close(x.grad, z["gx"], 1e-5, 1e-5, "dx")
+    close(w.grad, z["gw"], 1e-4, 1e-5, "dw")
+    close(b.grad, z["gb"], 1e-4, 1e-5, "db")
+
+
+# ================================================================================================ norm
+def test_instnorm_lrelu_fixture():
+    from multimodal_mvd_seg_amd import ops
+    z = load_npz("instnorm_lrelu.npz")
+    x, ga, be = G(z["x"], True), G(z["gamma"], True), G(z["beta"], True)
+    y = ops.InstanceNormLeakyReLUFn.apply(x, ga, be, 1e-5, 0.01)
+    close(y, z["y"], 1e-5, 1e-5, "y")
+    y.backward(G(z["gy"]))
+    close(x.grad, z["gx"], 1e-5, 1e-5, "dx")
+    close(ga.grad, z["ggamma"], 1e-4, 1e-5, "dgamma")
+    close(be.grad, z["gbeta"], 1e-4, 1e-5, "dbeta")
+
+
+def test_instnorm_lrelu_full_size_vs_oracle():
+    """largest instance on the path: [1,32,128^3] (268 MB); statistics over 2 097 152 voxels."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 32, 128, 128, 128, generator=g) * 1.7 + 0.3
+    gamma = torch.rand(32, generator=g) + 0.5
+    beta = torch.randn(32, generator=g) * 0.1
+    ref = F.leaky_relu(F.instance_norm(x, None, None, gamma, beta, True, 0.1, 1e-5), 0.01)
+    y = ops.InstanceNormLeakyReLUFn.apply(G(x), G(gamma), G(beta), 1e-5, 0.01)
+    close(y, ref, 1e-5, 1e-5, "y")
+    # run-to-run determinism (fixed-order reductions, no float atomics)
+    y2 = ops.InstanceNormLeakyReLUFn.apply(G(x), G(gamma), G(beta), 1e-5, 0.01)
+    assert torch.equal(y, y2)
+
+
+# ================================================================================================ losses
+def test_robust_ce_reference_fixture():
+    from multimodal_mvd_seg_amd import losses
+    z = load_npz("robust_ce.npz")
+    logits = G(z["logits"], True)
+    l = losses.RobustCrossEntropyLoss()(logits, G(z["target"]))
+    l.backward()
+    close(l, z["loss"], 1e-6, 1e-6, "loss")
+    close(logits.grad, z["glogits"], 1e-7, 1e-5, "dlogits")
+
+
+@pytest.mark.parametrize("bd", [0, 1])
+def test_dc_and_ce_fixture(bd):
+    from multimodal_mvd_seg_amd import losses, ops
+    z = load_npz(f"dc_ce_batchdice{bd}.npz")
+    logits = G(z["logits"], True)
+    lf = losses.DC_and_CE_loss({'batch_dice': bool(bd), 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {},
+                               weight_ce=1, weight_dice=1, ignore_label=None,
+                               dice_class=losses.MemoryEfficientSoftDiceLoss)
+    l = lf(logits, G(z["target"]))
+    l.backward()
+    close(l, z["loss"], 2e-6, 1e-6, "loss")
+    close(logits.grad, z["glogits"], 1e-7, 1e-4, "dlogits")
+    counts = ops.argmax_counts(logits.detach(), G(z["target"])).cpu().numpy()
+    assert np.array_equal(counts[1:, 0], z["tp"].astype(np.int64))  # integer counts: bit-exact
+    assert np.array_equal(counts[1:, 1], z["fp"].astype(np.int64))
+    assert np.array_equal(counts[1:, 2], z["fn"].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", ["distill_kl_c5_T1.npz", "distill_kl_c5_T4.npz", "distill_kl_c1_T1.npz",
+                                  "distill_kl_c1_T4.npz"])
+def test_distill_kl(name):
+    from multimodal_mvd_seg_amd import losses
+    z = load_npz(name)
+    ys, yt = G(z["ys"], True), G(z["yt"], True)
+    l = losses.distill_kl(ys, yt, int(z["T"]))
+    l.backward()
+    close(l, z["loss"], 1e-7, 1e-5, "loss")
+    close(ys.grad, z["gys"], 1e-8, 1e-4, "gys")
+    close(yt.grad, z["gyt"], 1e-8, 1e-4, "gyt")
+
+
+@pytest.mark.parametrize("name", ["feat_kl_T1.npz", "feat_kl_T4.npz"])
+def test_feature_kl_ndhwc(name):
+    from multimodal_mvd_seg_amd import losses, ops
+    z = load_npz(name)
+    a, b = G(z["a"]), G(z["b"])
+    a, b = ops.to_ndhwc(a).requires_grad_(), ops.to_ndhwc(b).requires_grad_()  # feature maps live in NDHWC
+    l = losses.l2_loss(a, b, channel_wise=True, T=int(z["T"]))
+    l.backward()
+    close(l, z["loss"], 1e-7, 1e-5, "loss")
+    close(a.grad, z["ga"], 1e-8, 1e-4, "ga")
+    close(b.grad, z["gb"], 1e-8, 1e-4, "gb")
+
+
+# ================================================================================================ soft skeleton
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.startswith("soft_skel_")))
+def test_soft_skel_reference_fixture(name):
+    from multimodal_mvd_seg_amd import losses
+    z = load_npz(name)
+    x = G(z["x"], True)
+    assert torch.equal(losses.soft_erode(x.detach()).cpu(), torch.from_numpy(z["erode"]))
+    assert torch.equal(losses.soft_dilate(x.detach()).cpu(), torch.from_numpy(z["dilate"]))
+    y = losses.soft_skel(x, int(z["iter"]))
+    assert torch.equal(y.detach().cpu(), torch.from_numpy(z["skel"])), "soft_skel forward must be bit-exact"
+    y.backward(G(z["gy"]))
+    close(x.grad, z["gx"], 1e-6, 1e-5, "gx")
+
+
+def test_soft_cldice_fixture():
+    from multimodal_mvd_seg_amd import losses
+    z = load_npz("soft_cldice.npz")
+    p = G(z["pred"], True)
+    l = losses.soft_cldice(p, G(z["target"]), int(z["iter"]), float(z["smooth"]))
+    l.backward()
+    close(l, z["loss"], 1e-6, 1e-5, "loss")
+    close(p.grad, z["gpred"], 1e-8, 1e-4, "gpred")
+
+
+# ================================================================================================ connected components
+def test_cc_label_fixture_bit_exact():
+    from multimodal_mvd_seg_amd import ops
+    d = json.load(open(os.path.join(GOLDEN, "cc_label.json")))
+    for case in d["cases"]:
+        mask = np.asarray(case["mask"], dtype=np.uint8).reshape(case["shape"])
+        labels, count = ops.cc_label(G(mask), case["conn"])
+        assert int(count.item()) == case["count"]
+        assert np.array_equal(labels.cpu().numpy().reshape(-1), np.asarray(case["labels"], dtype=np.int32))
+
+
+@pytest.mark.parametrize("conn", [6, 14, 26])
+def test_cc_label_large_vs_c_oracle(conn):
+    from multimodal_mvd_seg_amd import ops
+    from oracle import cc_oracle
+    rng = np.random.default_rng(5)
+    f = rng.random((48, 64, 56)).astype(np.float32)
+    for thr in (0.3, 0.7):  # near / far from the percolation threshold: few huge vs many small components
+        m = ops.threshold_mask(G(f), thr)
+        assert np.array_equal(m.cpu().numpy(), (f > thr).astype(np.uint8))
+        labels, count = ops.cc_label(m, conn)
+        ref_labels, ref_n = cc_oracle.cc_label(f > thr, conn)
+        assert int(count.item()) == ref_n
+        assert np.array_equal(labels.cpu().numpy(), ref_labels)
+    for fill in (0, 1):  # empty / full
+        labels, count = ops.cc_label(G(np.full((3, 4, 5), fill, dtype=np.uint8)), conn)
+        assert int(count.item()) == fill and int(labels.max().item()) == fill
+
+
+# ================================================================================================ optimizer
+def test_fused_sgd_matches_torch_sgd_with_clipping():
+    from multimodal_mvd_seg_amd import optim
+    torch.manual_seed(0)
+    shapes = [(33, 7, 3), (5,), (1023,), (64, 64)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    o_ref = torch.optim.SGD(ref, 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    o_mine = optim.FusedSGDNesterov(mine, 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True, max_grad_norm=12)
+    for step in range(4):
+        o_mine.zero_grad()
+        scale = 30.0 if step % 2 == 0 else 0.01  # clipped and un-clipped steps
+        for p, q in zip(ref, mine):
+            g = torch.randn(p.shape) * scale
+            p.grad = g.clone()
+            q.grad.copy_(g.to(DEV))
+        gn = torch.nn.utils.clip_grad_norm_(ref, 12)
+        o_ref.step()
+        o_mine.step()
+        assert abs(float(o_mine.grad_norm()) - float(gn)) <= 1e-4 * float(gn)
+        for p, q in zip(ref, mine):
+            close(q, p.detach(), 1e-6, 1e-6, f"param step {step}")
+
+
+# ================================================================================================ end to end
+def _mi355_net_from_fixture(z, in_ch, n_stages):
+    from multimodal_mvd_seg_amd import network
+    from torch import nn
+    net = network.MI355PlainConvUNet(in_ch, n_stages, z["features"].tolist(), nn.Conv3d, 3, z["strides"].tolist(), 2,
+                                     int(z["num_classes"]), 2, True, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
+                                     None, None, nn.LeakyReLU, {'inplace': True}, deep_supervision=True)
+    return net
+
+
+def test_unet_tiny_train_steps_match_oracle_fixture():
+    """inputs, initial state_dict -> logits list, loss, every gradient, parameters after 1 and 3 SGD steps."""
+    from multimodal_mvd_seg_amd import losses, optim
+    z = load_npz("unet_tiny_step.npz")
+    net = _mi355_net_from_fixture(z, 2, 3)
+    net.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0/")})
+    net.to(DEV)
+    opt = optim.FusedSGDNesterov(list(net.parameters()), 1e-2, weight_decay=3e-5, momentum=0.99, max_grad_norm=12)
+    loss_fn = losses.DeepSupervisionWrapper(
+        losses.DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False, 'ddp': False}, {}),
+        losses.ds_weights(2))
+    data, target = G(z["data"]), [G(z["target0"]), G(z["target1"])]
+    names = dict(net.named_parameters())
+    for step in range(3):
+        opt.zero_grad()
+        out = net(data)
+        l = loss_fn(out, target)
+        l.backward()
+        if step == 0:
+            for i, o in enumerate(out):
+                close(o, z[f"logits{i}"], 1e-4, 0, f"logits{i}")
+                assert o.is_contiguous() and tuple(o.shape) == tuple(z[f"logits{i}"].shape)
+            for n, p in names.items():
+                ref = z["grad0/" + n]
+                # conv bias before InstanceNorm has an analytically zero gradient (fp noise on both sides)
+                tol = 2e-5 if (n.endswith("conv.bias") or "all_modules.0.bias" in n) else 1e-4
+                close(p.grad, ref, tol * max(1.0, float(np.abs(ref).max())), 0, "grad " + n)
+        close(l, z[f"loss{step}"], 1e-5, 1e-5, f"loss{step}")
+        opt.step()
+        assert abs(float(opt.grad_norm()) - float(z[f"gradnorm{step}"])) < 1e-3 * float(z[f"gradnorm{step}"])
+        if step in (0, 2):
+            for n, p in names.items():
+                close(p, z[f"sd{step + 1}/" + n], 2e-5 if step == 0 else 1e-4, 0, f"param after step {step + 1}: {n}")
+    # Dice parity: identical argmax counts after the same three steps
+    from multimodal_mvd_seg_amd import ops
+    with torch.no_grad():
+        counts = ops.argmax_counts(net(data)[0], target[0]).cpu().numpy()
+    assert np.array_equal(counts[1:, 0], z["val_tp"].astype(np.int64))
+    assert np.array_equal(counts[1:, 1], z["val_fp"].astype(np.int64))
+    assert np.array_equal(counts[1:, 2], z["val_fn"].astype(np.int64))
+
+
+def test_unet_anisotropic_strides_forward():
+    z = load_npz("unet_aniso_fwd.npz")
+    net = _mi355_net_from_fixture(z, 1, 3)
+    net.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0/")})
+    net.to(DEV)
+    with torch.no_grad():
+        out = net(G(z["data"]))
+    for i, o in enumerate(out):
+        close(o, z[f"logits{i}"], 1e-4, 0, f"logits{i}")
+    net.decoder.deep_supervision = False  # bare tensor without DS (UNetDecoder.py:117-118)
+    with torch.no_grad():
+        o = net(G(z["data"]))
+    assert torch.is_tensor(o)
+    close(o, z["logits0"], 1e-4, 0, "logits (no DS)")
+
+
+def test_mvd_dual_branch_step_matches_oracle_fixture():
+    from multimodal_mvd_seg_amd import trainer
+    z = load_npz("mvd_tiny_step.npz")
+    plans = trainer.make_plans((16, 16, 16), z["strides"].tolist(), batch_size=2, base_features=8, max_features=32)
+    ds = {"channel_names": {"0": "a", "1": "b"}, "labels": {"background": 0, "l1": 1, "l2": 2, "l3": 3}}
+    tr = trainer.ContrastiveTrainerMI355(plans, "3d_fullres", 0, ds, device=DEV)
+    tr.initialize()
+    sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0/")}
+    tr.network.load_state_dict(sd0)
+    batch = {"data": G(z["data"]), "target": [G(z["target0"]), G(z["target1"])]}
+    tr.skel_iter = int(z["skel_iter"])
+    tr.on_train_epoch_start()
+    res = tr.train_step(batch)
+    assert abs(float(res["loss"]) - float(z["loss0"])) < 2e-5 * max(1.0, abs(float(z["loss0"])))
+    assert abs(float(tr.optimizer.grad_norm()) - float(z["gradnorm0"])) < 1e-3 * float(z["gradnorm0"])
+    for n, p in tr.network.named_parameters():
+        close(p, z["sd1/" + n], 2e-5, 0, "param after step 1: " + n)
+
+
+def test_cfg2_network_4x64cube_forward_backward_vs_oracle():
+    """The cfg-2 network (6 stages, 31.2 M parameters, 4 modalities) on a 64^3 patch against the torch-CPU oracle
+    evaluated on this box: logits within 1e-4, loss within 1e-5, every gradient within 1e-4 of its scale."""
+    from multimodal_mvd_seg_amd import trainer
+    from oracle import loss_oracle as LO, step_oracle as SO, unet_oracle as UO
+    strides = UO.CONFIGS["cfg2"]["strides"]
+    ora = UO.build_plainconv_unet(4, 5, 6, strides, seed=0)
+    batch = SO.synthetic_batch(1, 4, (64, 64, 64), strides, num_classes=5, seed=1234)
+    loss_fn = LO.build_loss(len(batch["target"]))
+    out_ref = ora(batch["data"])
+    l_ref = loss_fn(out_ref, batch["target"])
+    l_ref.backward()
+    plans = trainer.make_plans((64, 64, 64), strides, batch_size=1)
+    ds = {"channel_names": {str(i): str(i) for i in range(4)}, "labels": {"background": 0, "a": 1, "b": 2, "c": 3, "d": 4}}
+    tr = trainer.nnUNetTrainerMI355(plans, "3d_fullres", 0, ds, device=DEV)
+    tr.initialize()
+    tr.network.load_state_dict(ora.state_dict())
+    tr.optimizer.zero_grad()
+    data, target = batch["data"].to(DEV), [t.to(DEV) for t in batch["target"]]
+    out = tr.network(data)
+    l = tr.loss(out, target)
+    l.backward()
+    for i, (o, r) in enumerate(zip(out, out_ref)):
+        close(o, r.detach(), 1e-4, 0, f"logits{i}")
+    close(l, l_ref.detach(), 1e-5, 1e-5, "loss")
+    ref_grads = dict(ora.named_parameters())
+    for n, p in tr.network.named_parameters():
+        r = ref_grads[n].grad
+        scale = max(float(r.abs().max()), 1e-3)
+        tol = 1e-4 * scale if not n.endswith("conv.bias") else 1e-5
+        close(p.grad, r, tol, 0, "grad " + n)

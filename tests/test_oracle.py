@@ -1,0 +1,231 @@
+"""CPU tests: the oracle (oracle/) against the committed golden fixtures (tests/golden/), including the ones
+generated from reference modules (robust_ce, soft_skeleton, polylr, network_topology, C++ persistence)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, load_npz
+from oracle import cc_oracle, loss_oracle as LO, step_oracle as SO, unet_oracle as UO
+
+torch.set_num_threads(4)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_robust_ce_reference_fixture():
+    z = load_npz("robust_ce.npz")
+    logits = T(z["logits"]).requires_grad_()
+    l = LO.RobustCrossEntropyLoss()(logits, T(z["target"]))
+    l.backward()
+    assert torch.equal(l.detach(), T(z["loss"]))
+    assert torch.equal(logits.grad, T(z["glogits"]))
+
+
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.startswith("soft_skel_")))
+def test_soft_skel_reference_fixture(name):
+    z = load_npz(name)
+    x = T(z["x"]).requires_grad_()
+    y = LO.soft_skel(x, int(z["iter"]))
+    assert torch.equal(y.detach(), T(z["skel"]))  # bit-exact: min/max/relu/sub/mul/add only
+    y.backward(T(z["gy"]))
+    assert torch.equal(x.grad, T(z["gx"]))
+    assert torch.equal(LO.soft_erode(x.detach()), T(z["erode"]))
+    assert torch.equal(LO.soft_dilate(x.detach()), T(z["dilate"]))
+
+
+def test_polylr_reference_fixture():
+    d = json.load(open(os.path.join(GOLDEN, "polylr.json")))
+    for e, lr in enumerate(d["lrs"]):
+        assert SO.poly_lr(d["initial_lr"], e, d["max_steps"]) == lr
+
+
+def test_topology_reference_fixture():
+    d = json.load(open(os.path.join(GOLDEN, "topology_props.json")))["props"]
+    for cfg in ("cfg1", "cfg2", "cfg5"):
+        assert d[cfg]["pool_op_kernel_sizes"] == UO.CONFIGS[cfg]["strides"]
+        assert all(k == [3, 3, 3] for k in d[cfg]["conv_kernel_sizes"])
+        assert len(d[cfg]["conv_kernel_sizes"]) == UO.CONFIGS[cfg]["n_stages"]
+    # the author's patch 64x128x256 ends with a (1,2,2) pooling -> per-axis strides are a real requirement
+    assert d["author"]["pool_op_kernel_sizes"][-1] == [1, 2, 2]
+
+
+def test_he_init_reference_fixture():
+    d = json.load(open(os.path.join(GOLDEN, "he_init_stats.json")))["stats"]
+    torch.manual_seed(0)
+    net = UO.build_plainconv_unet(4, 5, 3, [[1, 1, 1], [2, 2, 2], [2, 2, 2]], seed=0)
+    for m in net.modules():
+        if isinstance(m, (torch.nn.Conv3d, torch.nn.ConvTranspose3d)):
+            assert float(m.bias.abs().max()) == 0.0
+    for name, st in d.items():
+        assert abs(st["std"] - st["expected_std"]) / st["expected_std"] < 0.15
+        assert st["bias_abs_max"] == 0.0
+
+
+def test_param_counts_match_survey():
+    n1 = UO.build_plainconv_unet(1, 5, 5, UO.CONFIGS["cfg1"]["strides"])
+    n2 = UO.build_plainconv_unet(4, 5, 6, UO.CONFIGS["cfg2"]["strides"])
+    c1 = sum(p.numel() for p in n1.parameters())
+    c2 = sum(p.numel() for p in n2.parameters())
+    assert abs(c1 - 16.55e6) < 0.02e6 and abs(c2 - 31.20e6) < 0.02e6
+    keys = set(n2.state_dict().keys())
+    for k in ("encoder.stages.0.0.convs.0.conv.weight", "encoder.stages.0.0.convs.0.all_modules.0.weight",
+              "encoder.stages.5.0.convs.1.norm.bias", "decoder.encoder.stages.0.0.convs.0.conv.weight",
+              "decoder.stages.0.convs.0.conv.weight", "decoder.transpconvs.4.weight", "decoder.seg_layers.4.bias"):
+        assert k in keys, k
+
+
+@pytest.mark.parametrize("name", ["distill_kl_c5_T1.npz", "distill_kl_c5_T4.npz", "distill_kl_c1_T1.npz",
+                                  "distill_kl_c1_T4.npz"])
+def test_distill_kl_fixture(name):
+    z = load_npz(name)
+    ys, yt = T(z["ys"]).requires_grad_(), T(z["yt"]).requires_grad_()
+    l = LO.distill_kl(ys, yt, int(z["T"]))
+    l.backward()
+    assert torch.allclose(l.detach(), T(z["loss"]), rtol=1e-6, atol=0)
+    assert torch.allclose(ys.grad, T(z["gys"]), rtol=1e-5, atol=1e-9)
+
+
+def test_dc_ce_fixture_and_dice_counts():
+    for bd in (0, 1):
+        z = load_npz(f"dc_ce_batchdice{bd}.npz")
+        logits = T(z["logits"]).requires_grad_()
+        l = LO.build_loss(1, batch_dice=bool(bd), deep_supervision=False)(logits, T(z["target"]))
+        l.backward()
+        assert torch.allclose(l.detach(), T(z["loss"]), rtol=1e-6)
+        assert torch.allclose(logits.grad, T(z["glogits"]), rtol=1e-5, atol=1e-9)
+        tp, fp, fn = LO.validation_counts(logits.detach(), T(z["target"]))
+        assert np.array_equal(tp, z["tp"]) and np.array_equal(fp, z["fp"]) and np.array_equal(fn, z["fn"])
+        assert abs(LO.dice_from_counts(tp, fp, fn)[1] - float(z["dice_mean"])) < 1e-12
+
+
+def test_ds_weights():
+    assert np.allclose(LO.ds_weights(5), [0.53333333, 0.26666667, 0.13333333, 0.06666667, 0.0])
+    assert np.allclose(LO.ds_weights(4), [0.57142857, 0.28571429, 0.14285714, 0.0])
+
+
+def test_unet_tiny_step_fixture():
+    z = load_npz("unet_tiny_step.npz")
+    strides = z["strides"].tolist()
+    net = UO.build_plainconv_unet(2, int(z["num_classes"]), 3, strides, features_per_stage=z["features"].tolist())
+    net.load_state_dict({k[4:]: T(z[k]) for k in z.files if k.startswith("sd0/")})
+    batch = {"data": T(z["data"]), "target": [T(z[f"target{i}"]) for i in range(2)]}
+    ref = SO.synthetic_batch(2, 2, (16, 16, 16), strides, num_classes=3, seed=1234)
+    assert torch.equal(ref["data"], batch["data"]) and torch.equal(ref["target"][1], batch["target"][1])
+    loss_fn = LO.build_loss(2)
+    opt = SO.make_optimizer(net.parameters())
+    l, logits, gn = SO.train_step(net, loss_fn, opt, batch)
+    assert abs(float(l) - float(z["loss0"])) < 1e-6
+    assert torch.allclose(logits[0], T(z["logits0"]), atol=1e-5)
+    for n, p in net.named_parameters():
+        assert torch.allclose(p.detach(), T(z["sd1/" + n]), atol=1e-6), n
+
+
+def test_ddp_split_fixture():
+    d = json.load(open(os.path.join(GOLDEN, "ddp_split.json")))["cases"]
+    for key, v in d.items():
+        gb, ws = map(int, key.split("_"))
+        bs, ov = SO.ddp_batch_split(gb, ws)
+        assert bs == v["batch_sizes"] and np.allclose(ov, v["oversample"])
+        if gb % ws == 0:  # (the reference's remainder rule can go negative for odd splits; mirrored, not fixed)
+            assert sum(bs) == gb
+
+
+def _sorted_pairs(b, d):
+    a = np.stack([b, d], 1)
+    return a[np.lexsort((a[:, 1], a[:, 0]))]
+
+
+def test_persistence_reference_fixture():
+    """oracle/cc_oracle.c against diagrams produced by the reference's own C++ (hom.cpp / cohom.cpp)."""
+    d = json.load(open(os.path.join(GOLDEN, "persistence_grid.json")))
+    for case in d["cases"]:
+        f = np.asarray(case["f"], dtype=np.float32).reshape(case["shape"])
+        b, de, _ = cc_oracle.h0_persistence(f, case["conn"])
+        want = np.array([[x, np.inf if y is None else y] for x, y in case["dgm0_sorted"]], dtype=np.float32)
+        assert np.array_equal(_sorted_pairs(b, de), want)
+    # the survey's known answer on the 5-vertex line: (0,inf),(0.5,3),(1,2),(2,2),(3,3)
+    last = d["cases"][-1]["dgm0_sorted"]
+    assert [tuple(p) for p in last] == [(0.0, None), (0.5, 3.0), (1.0, 2.0), (2.0, 2.0), (3.0, 3.0)]
+
+
+def test_cc_label_fixture():
+    d = json.load(open(os.path.join(GOLDEN, "cc_label.json")))
+    for case in d["cases"]:
+        mask = np.asarray(case["mask"], dtype=np.uint8).reshape(case["shape"])
+        labels, n = cc_oracle.cc_label(mask, case["conn"])
+        assert n == case["count"]
+        assert np.array_equal(labels.reshape(-1), np.asarray(case["labels"], dtype=np.int32))
+
+
+def test_cc_label_edge_cases():
+    for shape in ((1, 1, 1), (1, 1, 7), (3, 1, 2)):
+        for fill in (0, 1):
+            m = np.full(shape, fill, dtype=np.uint8)
+            labels, n = cc_oracle.cc_label(m, 6)
+            assert n == fill and labels.max() == fill
+    # count == number of essential H0 bars of the masked sub-level set
+    rng = np.random.default_rng(3)
+    f = rng.random((5, 6, 7)).astype(np.float32)
+    _, death, _ = cc_oracle.h0_persistence(f, 6)
+    assert int(np.isinf(death).sum()) == 1
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree only exists in the build container")
+def test_oracle_against_live_reference_modules():
+    import importlib.util
+    R = "/root/reference/nnUNet/nnunetv2"
+
+    def ref(rel, name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(R, rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    sk = ref("training/loss/soft_skeleton.py", "ref_skel_live")
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 2, 9, 8, 7, generator=g)
+    for it in (0, 2, 5):
+        assert torch.equal(sk.soft_skel(x, it), LO.soft_skel(x, it))
+    rce = ref("training/loss/robust_ce_loss.py", "ref_rce_live")
+    logits = torch.randn(2, 4, 3, 3, 3, generator=g)
+    tgt = torch.round(torch.rand(2, 1, 3, 3, 3, generator=g) * 3)
+    assert torch.equal(rce.RobustCrossEntropyLoss()(logits, tgt), LO.RobustCrossEntropyLoss()(logits, tgt))
+    init = ref("utilities/network_initialization.py", "ref_init_live")
+    torch.manual_seed(11)
+    a = torch.nn.Conv3d(4, 8, 3)
+    a.apply(init.InitWeights_He(1e-2))
+    torch.manual_seed(11)
+    b = torch.nn.Conv3d(4, 8, 3)
+    b.apply(UO.InitWeights_He(1e-2))
+    assert torch.equal(a.weight, b.weight)
+
+
+def test_ref_extension_if_built():
+    """oracle/_ref (the reference's C++ compiled by oracle/build_ref.py) agrees with the C oracle."""
+    from oracle import build_ref
+    m = build_ref.load()
+    if m is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(9)
+    D, H, W = 3, 4, 5
+    f = (np.round(rng.random((D, H, W)) * 8) / 8).astype(np.float32)  # ties on purpose
+    s = m.SimplicialComplex()
+    for i in range(D * H * W):
+        s.append([i])
+    for z in range(D):
+        for y in range(H):
+            for x in range(W):
+                for dz, dy, dx in ((0, 0, 1), (0, 1, 0), (1, 0, 0)):
+                    if z + dz < D and y + dy < H and x + dx < W:
+                        s.append([(z * H + y) * W + x, ((z + dz) * H + y + dy) * W + x + dx])
+    s.initialize()
+    s.extendFloat(torch.from_numpy(f.reshape(-1).copy()))
+    dgm = m.persistenceForwardHom(s, 0, 0)[0].detach().numpy()
+    b, de, _ = cc_oracle.h0_persistence(f, 6)
+    assert np.array_equal(dgm[np.lexsort((dgm[:, 1], dgm[:, 0]))], _sorted_pairs(b, de))
