@@ -67,7 +67,8 @@ def dominant_kernel_roofline(torch, dev):
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def conv():
-        call("mvd_conv3d_fwd", P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, D, H, W, K, i3((3, 3, 3)), i3((1, 1, 1)), s)
+        call("mvd_conv3d_fwd", P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, D, H, W, K, i3((3, 3, 3)), i3((1, 1, 1)),
+             None, 0, s)
     ms = time_kernel(conv, 3, torch)
     flops = 2.0 * 27 * (C1 + C2) * K * N * D * H * W
     conv_tf = flops / (ms * 1e-3) / 1e12

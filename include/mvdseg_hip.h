@@ -49,11 +49,16 @@ int mvd_pack_weight(const float *w, float *wf, float *wb, int K, int C, int T, i
  * concatenation of x1 [N,D,H,W,C1] and x2 [N,D,H,W,C2] (x2 may be NULL with C2 = 0).
  *   y[n,o,k] = bias[k] + sum_t sum_c x[n, o*s + t - pad, c] * wf[t][c][k],   y: [N,Do,Ho,Wo,K]
  * Do = (D + 2*pad - k)/s + 1. */
+/* ws (optional, may be NULL): scratch for the split-reduce path the engine takes on skinny problems (few output
+ * voxels, hundreds of reduce channels: the 8^3 / 4^3 stages); size from mvd_conv_fwd_workspace_bytes(N, output voxels
+ * per sample, output channels).  Same for dgrad / convT fwd / convT dgrad (output = the tensor being produced). */
+size_t mvd_conv_fwd_workspace_bytes(int N, long out_voxels, int K);
 int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *bias, float *y,
-                   int N, int D, int H, int W, int K, const int ksize[3], const int stride[3], void *stream);
+                   int N, int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws,
+                   size_t ws_bytes, void *stream);
 /* dgrad: dx = conv_transpose(dy, w); written as dx1 [.,C1] and dx2 [.,C2] (channel split of the concat). */
 int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float *dx2, int C2, int N, int D, int H,
-                     int W, int K, const int ksize[3], const int stride[3], void *stream);
+                     int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream);
 /* wgrad: dw in TORCH layout [K][C1+C2][T], dbias [K] (may be NULL).  Fixed-order split reduction through `ws`. */
 size_t mvd_conv3d_wgrad_workspace_bytes(int C, int K, int T, int N, int Do, int Ho, int Wo);
 int mvd_conv3d_wgrad(const float *x1, int C1, const float *x2, int C2, const float *dy, float *dw, float *dbias,
@@ -65,9 +70,9 @@ int mvd_conv3d_wgrad(const float *x1, int C1, const float *x2, int C2, const flo
  * (UNetDecoder.py:56-59,106).  x: [N,D,H,W,C] -> y: [N,D*s0,H*s1,W*s2,K];  wf[T][C][K], T = s0*s1*s2.
  *   y[n, q*s + p, k] = bias[k] + sum_c x[n,q,c] * w[c][k][p] */
 int mvd_convT3d_fwd(const float *x, const float *wf, const float *bias, float *y, int N, int D, int H, int W, int C,
-                    int K, const int stride[3], void *stream);
+                    int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
 int mvd_convT3d_dgrad(const float *dy, const float *wb, float *dx, int N, int D, int H, int W, int C, int K,
-                      const int stride[3], void *stream);
+                      const int stride[3], void *ws, size_t ws_bytes, void *stream);
 size_t mvd_convT3d_wgrad_workspace_bytes(int C, int K, int T, int N, int D, int H, int W);
 /* dw in TORCH layout [C][K][T], dbias [K] */
 int mvd_convT3d_wgrad(const float *x, const float *dy, float *dw, float *dbias, int N, int D, int H, int W, int C,

@@ -20,13 +20,16 @@ SIGNATURES = {
     "mvd_has_mfma": (c_int, []),
     "mvd_set_conv_engine": (c_int, [c_int]),
     "mvd_pack_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "mvd_conv3d_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P]),
-    "mvd_conv3d_dgrad": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P]),
+    "mvd_conv_fwd_workspace_bytes": (c_size_t, [c_int, c_long, c_int]),
+    "mvd_conv3d_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
+                               c_size_t, _P]),
+    "mvd_conv3d_dgrad": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
+                                 c_size_t, _P]),
     "mvd_conv3d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mvd_conv3d_wgrad": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                  c_size_t, _P]),
-    "mvd_convT3d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P]),
-    "mvd_convT3d_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P]),
+    "mvd_convT3d_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
+    "mvd_convT3d_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
     "mvd_convT3d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mvd_convT3d_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
     "mvd_instnorm_nblk": (c_int, [c_int, c_long, c_int]),
@@ -78,6 +81,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be
+    # in the process BEFORE our library is opened so that the dynamic loader binds our DT_NEEDED libamdhip64.so.7 to
+    # that same copy: two HIP runtimes in one process cannot share streams or allocations (the second one reports
+    # "no ROCm-capable device").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "

@@ -28,7 +28,13 @@ inline int check_launch(const char *what) {
         }                                 \
     } while (0)
 
-inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+// Every entry point converts its stream argument first; that is also where a stale (sticky, already reported or
+// benign) error of an earlier HIP call in this thread -- e.g. one of PyTorch's own probes -- is cleared, so that
+// check_launch() only ever reports the status of OUR launch.
+inline hipStream_t as_stream(void *s) {
+    (void)hipGetLastError();
+    return reinterpret_cast<hipStream_t>(s);
+}
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 

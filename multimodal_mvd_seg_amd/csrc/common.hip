@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include "conv_geom.h"
 
 namespace mvd {
 
@@ -75,7 +76,7 @@ __global__ void k_axpy(float *__restrict__ y, const float *__restrict__ x, float
     for (; i < n; i += stride) y[i] = y[i] + a * x[i];
 }
 
-// torch [K][C][T] (or transposed-conv [C][K][T]) -> wf[T][C][K], wb[T][K][C]
+// torch [K][C][T] (or transposed-conv [C][K][T]) -> wf / wb in the packed layout of conv_geom.h (widx)
 __global__ void k_pack_weight(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wb, int K,
                               int C, int T, int transposed) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,8 +87,8 @@ __global__ void k_pack_weight(const float *__restrict__ w, float *__restrict__ w
     int c = (i / K) % C;
     int t = i / ((long)K * C);
     float v = transposed ? w[((size_t)c * K + k) * T + t] : w[((size_t)k * C + c) * T + t];
-    if (wf) wf[i] = v;
-    if (wb) wb[((size_t)t * K + k) * C + c] = v;
+    if (wf) wf[widx(wl_ck(C), T, C, K, t, c, k)] = v;  // reduce over C, produce K
+    if (wb) wb[widx(wl_ck(K), T, K, C, t, k, c)] = v;  // reduce over K, produce C
 }
 
 }  // namespace mvd

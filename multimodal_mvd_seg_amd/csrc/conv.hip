@@ -13,6 +13,7 @@ __global__ void k_fwd_scalar(FwdGeom g, const float *__restrict__ a1, const floa
                              const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ y1,
                              float *__restrict__ y2) {
     const int K = g.K1 + g.K2, C = g.C1 + g.C2;
+    const int CK = wl_ck(C);
     const long total = (long)g.N * g.Do * g.Ho * g.Wo * K;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         int k = (int)(idx % K);
@@ -28,13 +29,12 @@ __global__ void k_fwd_scalar(FwdGeom g, const float *__restrict__ a1, const floa
             int id = od * g.sa[0] + g.off[t][0], ih = oh * g.sa[1] + g.off[t][1], iw = ow * g.sa[2] + g.off[t][2];
             if (id < 0 || id >= g.Di || ih < 0 || ih >= g.Hi || iw < 0 || iw >= g.Wi) continue;
             size_t vox = (((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw;
-            const float *wt = w + (size_t)g.wt[t] * C * K + k;
+            const int tw = g.wt[t];
             const float *p1 = a1 + vox * g.C1;
-            for (int c = 0; c < g.C1; c++) acc += p1[c] * wt[(size_t)c * K];
+            for (int c = 0; c < g.C1; c++) acc += p1[c] * w[widx(CK, g.T, C, K, tw, c, k)];
             if (g.C2) {
                 const float *p2 = a2 + vox * g.C2;
-                const float *wt2 = wt + (size_t)g.C1 * K;
-                for (int c = 0; c < g.C2; c++) acc += p2[c] * wt2[(size_t)c * K];
+                for (int c = 0; c < g.C2; c++) acc += p2[c] * w[widx(CK, g.T, C, K, tw, g.C1 + c, k)];
             }
         }
         size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
@@ -170,10 +170,49 @@ __global__ void k_colsum(const float *__restrict__ x, double *__restrict__ parti
     }
 }
 
+// K % 4 == 0, K <= 1024: float4 loads, several rows in flight per thread (HBM-bound streaming pass)
+__global__ void k_colsum4(const float *__restrict__ x, double *__restrict__ partial, long rows, int K, long chunk) {
+    extern __shared__ double sm4[];  // [R][K]
+    const int t = threadIdx.x;
+    const int KG = K / 4;
+    const int R = blockDim.x / KG;
+    const int g = t % KG, r = t / KG;
+    const long r0 = (long)blockIdx.x * chunk;
+    long r1 = r0 + chunk;
+    if (r1 > rows) r1 = rows;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (r < R) {
+        const float *xp = x + (size_t)g * 4;
+        long i = r0 + r;
+        for (; i + 3L * R < r1; i += 4L * R) {
+            float4 q0 = *reinterpret_cast<const float4 *>(xp + (size_t)i * K);
+            float4 q1 = *reinterpret_cast<const float4 *>(xp + (size_t)(i + R) * K);
+            float4 q2 = *reinterpret_cast<const float4 *>(xp + (size_t)(i + 2L * R) * K);
+            float4 q3 = *reinterpret_cast<const float4 *>(xp + (size_t)(i + 3L * R) * K);
+            a0 += (double)((q0.x + q1.x) + (q2.x + q3.x));
+            a1 += (double)((q0.y + q1.y) + (q2.y + q3.y));
+            a2 += (double)((q0.z + q1.z) + (q2.z + q3.z));
+            a3 += (double)((q0.w + q1.w) + (q2.w + q3.w));
+        }
+        for (; i < r1; i += R) {
+            float4 q = *reinterpret_cast<const float4 *>(xp + (size_t)i * K);
+            a0 += (double)q.x; a1 += (double)q.y; a2 += (double)q.z; a3 += (double)q.w;
+        }
+        double *o = sm4 + (size_t)r * K + g * 4;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    }
+    __syncthreads();
+    for (int k = t; k < K; k += blockDim.x) {
+        double s = 0;
+        for (int rr = 0; rr < R; rr++) s += sm4[(size_t)rr * K + k];
+        partial[(size_t)blockIdx.x * K + k] = s;
+    }
+}
+
 static int colsum_blocks(long rows, long *chunk) {
-    long nb = rows / 1024;
+    long nb = rows / 256;
     if (nb < 1) nb = 1;
-    if (nb > 512) nb = 512;
+    if (nb > 2048) nb = 2048;
     *chunk = cdiv(rows, nb);
     return (int)cdiv(rows, *chunk);
 }
@@ -185,7 +224,15 @@ static int colsum(const float *x, float *out, long rows, int K, void *ws, hipStr
     long chunk;
     int nb = colsum_blocks(rows, &chunk);
     double *partial = reinterpret_cast<double *>(ws);
-    hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, x, partial, rows, K, chunk);
+    if (K % 4 == 0 && K <= 1024 && (((uintptr_t)x) & 15) == 0) {
+        const int KG = K / 4;
+        const int R = 256 / KG > 0 ? 256 / KG : 1;
+        const int threads = (R * KG + 63) / 64 * 64;
+        hipLaunchKernelGGL(k_colsum4, dim3(nb), dim3(threads), (size_t)R * K * sizeof(double), s, x, partial, rows, K,
+                           chunk);
+    } else {
+        hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, x, partial, rows, K, chunk);
+    }
     if (check_launch("bias grad")) return 1;
     return reduce_partials(partial, out, nb, K, s);
 }
@@ -225,7 +272,7 @@ static void conv_fwd_geom(FwdGeom &g, int N, int D, int H, int W, int C1, int C2
                 g.wt[t] = t;
                 t++;
             }
-    g.ntaps = t;
+    g.ntaps = g.T = t;
     for (int a = 0; a < 3; a++) {
         g.sa[a] = st[a];
         g.so[a] = 1;
@@ -234,9 +281,9 @@ static void conv_fwd_geom(FwdGeom &g, int N, int D, int H, int W, int C1, int C2
 }
 
 static int run_fwd(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
-                   float *y2, hipStream_t s) {
+                   float *y2, void *ws, size_t ws_bytes, hipStream_t s) {
     if (g_engine_mode == 0) {
-        int r = fwd_mfma(g, a1, a2, w, bias, y1, y2, s);
+        int r = fwd_mfma(g, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
         if (r >= 0) return r;
     }
     return fwd_scalar(g, a1, a2, w, bias, y1, y2, s);
@@ -264,18 +311,21 @@ int mvd_set_conv_engine(int mode) {
     return 0;
 }
 
+size_t mvd_conv_fwd_workspace_bytes(int N, long out_voxels, int K) { return fwd_mfma_ws(N, out_voxels, K); }
+
 int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *bias, float *y, int N,
-                   int D, int H, int W, int K, const int ksize[3], const int stride[3], void *stream) {
+                   int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                   void *stream) {
     MVD_REQUIRE(x1 && wf && y && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_fwd: null pointer / bad channels");
     MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_fwd: bad shape");
     if (check_ks(ksize, stride, "conv3d_fwd")) return 2;
     FwdGeom g;
     conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
-    return run_fwd(g, x1, x2, wf, bias, y, nullptr, as_stream(stream));
+    return run_fwd(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream));
 }
 
 int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float *dx2, int C2, int N, int D, int H, int W,
-                     int K, const int ksize[3], const int stride[3], void *stream) {
+                     int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(dy && wb && dx1 && C1 > 0 && C2 >= 0 && (C2 == 0 || dx2), "conv3d_dgrad: null pointer / bad channels");
     MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_dgrad: bad shape");
     if (check_ks(ksize, stride, "conv3d_dgrad")) return 2;
@@ -325,7 +375,9 @@ int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float
                             nt++;
                         }
                 g.ntaps = nt;
-                int r = run_fwd(g, dy, nullptr, wb, nullptr, dx1, dx2, as_stream(stream));
+                g.T = ksize[0] * ksize[1] * ksize[2];
+                if (nt == 0) continue;
+                int r = run_fwd(g, dy, nullptr, wb, nullptr, dx1, dx2, ws, ws_bytes, as_stream(stream));
                 if (r) return r;
             }
     return 0;
@@ -385,7 +437,7 @@ int mvd_conv3d_wgrad(const float *x1, int C1, const float *x2, int C2, const flo
 
 // ------------------------------------------------------------------------------------------------ ConvTranspose3d k == s
 int mvd_convT3d_fwd(const float *x, const float *wf, const float *bias, float *y, int N, int D, int H, int W, int C, int K,
-                    const int stride[3], void *stream) {
+                    const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(x && wf && y && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_fwd: bad arguments");
     for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_fwd: stride must be 1 or 2");
     for (int pd = 0; pd < stride[0]; pd++)
@@ -398,6 +450,7 @@ int mvd_convT3d_fwd(const float *x, const float *wf, const float *bias, float *y
                 g.Dy = D * stride[0]; g.Hy = H * stride[1]; g.Wy = W * stride[2];
                 g.C1 = C; g.K1 = K;
                 g.ntaps = 1;
+                g.T = stride[0] * stride[1] * stride[2];
                 g.wt[0] = (int8_t)((pd * stride[1] + ph) * stride[2] + pw);
                 const int p[3] = {pd, ph, pw};
                 for (int a = 0; a < 3; a++) {
@@ -405,14 +458,14 @@ int mvd_convT3d_fwd(const float *x, const float *wf, const float *bias, float *y
                     g.so[a] = stride[a];
                     g.oo[a] = p[a];
                 }
-                int r = run_fwd(g, x, nullptr, wf, bias, y, nullptr, as_stream(stream));
+                int r = run_fwd(g, x, nullptr, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream));
                 if (r) return r;
             }
     return 0;
 }
 
 int mvd_convT3d_dgrad(const float *dy, const float *wb, float *dx, int N, int D, int H, int W, int C, int K,
-                      const int stride[3], void *stream) {
+                      const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(dy && wb && dx && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_dgrad: bad arguments");
     for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_dgrad: stride must be 1 or 2");
     FwdGeom g;
@@ -429,13 +482,13 @@ int mvd_convT3d_dgrad(const float *dy, const float *wb, float *dx, int N, int D,
                 g.wt[t] = t;
                 t++;
             }
-    g.ntaps = t;
+    g.ntaps = g.T = t;
     for (int a = 0; a < 3; a++) {
         g.sa[a] = stride[a];
         g.so[a] = 1;
         g.oo[a] = 0;
     }
-    return run_fwd(g, dy, nullptr, wb, nullptr, dx, nullptr, as_stream(stream));
+    return run_fwd(g, dy, nullptr, wb, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream));
 }
 
 static void convT_wgrad_geom(WgradGeom &g, int N, int D, int H, int W, int C, int K, const int st[3]) {

@@ -13,8 +13,26 @@
 
 namespace mvd {
 
+// Packed weight layout shared by mvd_pack_weight, the scalar engine and the MFMA engine.  For a reduce dimension
+// C (multiple of 4) the tensor is stored in chunks of CK = 8 (or 4) reduce-channels, each chunk tap-major, and inside
+// a (chunk, tap) as [h][k][e] with c = cc*CK + h*(CK/2) + e: exactly the image one workgroup stages into LDS and
+// the order the 32x32x2 fp32 MFMA consumes (lane half h takes CK/2 consecutive k-steps from one ds_read_b128/b64).
+// C % 4 != 0 falls back to plain [t][c][k] (scalar engine only).
+// CK = 32 whenever possible: a 32-channel chunk of an NDHWC voxel is one whole 128-byte line, so the staging pass of
+// the MFMA kernels touches every input line exactly once (8-channel chunks re-fetched each line 4 times from HBM).
+__host__ __device__ inline int wl_ck(int C) {
+    return (C % 32 == 0) ? 32 : ((C % 8 == 0) ? 8 : ((C % 4 == 0) ? 4 : 0));
+}
+__host__ __device__ inline size_t widx(int CK, int T, int C, int K, int t, int c, int k) {
+    if (CK == 0) return ((size_t)t * C + c) * K + k;
+    const int hh = CK / 2;
+    const int cc = c / CK, r = c % CK;
+    return ((((size_t)cc * T + t) * 2 + r / hh) * K + k) * hh + (r % hh);
+}
+
 struct FwdGeom {
     int N;
+    int T;  // taps of the full weight tensor (packed-layout stride)
     int Di, Hi, Wi;
     int Do, Ho, Wo;
     int Dy, Hy, Wy;
@@ -42,8 +60,10 @@ struct WgradGeom {
 // engines (return 0 ok, >0 error, -1 = shape not supported by this engine)
 int fwd_scalar(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
                float *y2, hipStream_t s);
+// ws/ws_bytes: optional scratch for the split-reduce path of skinny problems (few tiles, many reduce channels)
+size_t fwd_mfma_ws(int N, long out_vox, int K);
 int fwd_mfma(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1, float *y2,
-             hipStream_t s);
+             void *ws, size_t ws_bytes, hipStream_t s);
 size_t wgrad_scalar_ws(const WgradGeom &g);
 int wgrad_scalar(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws,
                  size_t ws_bytes, hipStream_t s);

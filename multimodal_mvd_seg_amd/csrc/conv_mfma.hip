@@ -1,13 +1,952 @@
-// fp32 MFMA implicit-GEMM conv engines (placeholder until the kernels land: returns "unsupported").
+// fp32 MFMA implicit-GEMM conv engines for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+// Forward-type kernel (conv fwd, conv dgrad per parity class, convT fwd per class, convT dgrad):
+//   workgroup = 4 waves = one 4 x (4*MT) x 8 tile of the iteration grid x (32*NT) output channels.
+//   Loop over reduce-channel chunks of CK: stage the input halo tile [slots][CK] and the weight slice
+//   [taps][h][32*NT][CK/2] into LDS (the packed weight layout of conv_geom.h makes the latter a linear copy), then
+//   for every tap each wave issues MT*NT*(CK/2) MFMAs from ds_read_b128/b64 fragments (the k order inside a chunk is
+//   permuted identically for A and B, so one wide LDS read feeds CK/2 k-steps).  Single LDS buffer; latency is hidden
+//   by 2-3 co-resident workgroups per CU (LDS <= 75 KB each), not by in-kernel double buffering.
+// Wgrad-type kernel (conv wgrad, convT wgrad):
+//   workgroup = one 32(c) x 32(k) block of dW for all taps; taps are dealt round-robin to the 4 waves (<= 7 x 16
+//   accumulator registers each); the GEMM K dimension is the voxel index: each workgroup walks a strided subset of
+//   spatial tiles (split-K), staging the A halo [slots][32 c] and B tile [slots][32 k] in LDS, and writes fp32 partials;
+//   a fixed-order second stage sums the splits in fp64 and emits the torch weight layout (deterministic, no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_geom.h"
 
 namespace mvd {
-int fwd_mfma(const FwdGeom &, const float *, const float *, const float *, const float *, float *, float *, hipStream_t) {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct FwdTile {
+    int ED, EH, EW, nslots;
+    int min_off[3];
+    int ntd, nth, ntw;
+    int K;  // produce channels of the launch (K1+K2)
+    int toff[27];
+    int dbg;  // timing experiments only (MVD_CONV_DBG): bit0 skip staging loads, bit1 skip the MFMA loop
+};
+
+// L32: the packed weights use the CK = 32 layout (C % 32 == 0) but this kernel still walks 8-channel sub-chunks
+// {sc*4..sc*4+3} u {16+sc*4..16+sc*4+3} of each 32-chunk (used for the wide-halo stride-2 geometries only).
+template <int CK, int NT, int MT, bool L32>
+__global__ __launch_bounds__(256, 2) void k_fwd_mfma(const FwdGeom g, const FwdTile tg, const float *__restrict__ a1,
+                                                     const float *__restrict__ a2, const float *__restrict__ w,
+                                                     const float *__restrict__ bias, float *__restrict__ y1,
+                                                     float *__restrict__ y2, const int S, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int HH = CK / 2;
+    constexpr int KT = 32 * NT;
+    float *Xs = lds;
+    float *Ws = lds + (size_t)tg.nslots * CK;
+    int *tapoff = reinterpret_cast<int *>(Ws + (size_t)g.ntaps * 2 * KT * HH);
+    int *wts = tapoff + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    const int tw_ = tile % tg.ntw, th_ = (tile / tg.ntw) % tg.nth, td_ = tile / (tg.ntw * tg.nth);
+    // blockIdx.y = kb + nkb * split: skinny problems split the reduce-channel chunks over S workgroups (fixed-order
+    // second stage in k_split_reduce)
+    const int nkb = tg.K / (32 * NT);
+    const int kb = blockIdx.y % nkb, split = blockIdx.y / nkb, n = blockIdx.z;
+    const int od0 = td_ * 4, oh0 = th_ * (4 * MT), ow0 = tw_ * 8;
+    const int iz0 = od0 * g.sa[0] + tg.min_off[0], iy0 = oh0 * g.sa[1] + tg.min_off[1],
+              ix0 = ow0 * g.sa[2] + tg.min_off[2];
+#pragma unroll
+    for (int t = 0; t < 27; t++)
+        if (tid == t && t < g.ntaps) {
+            tapoff[t] = tg.toff[t];
+            wts[t] = g.wt[t];
+        }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][q][r] = 0.f;
+
+    int sbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const int hy = 4 * m + (i >> 3), wx = i & 7;
+        sbase[m] = ((wave * g.sa[0]) * tg.EH + hy * g.sa[1]) * tg.EW + wx * g.sa[2];
+    }
+
+    const int C = g.C1 + g.C2;
+    const int nch = C / CK;  // (L32: CK == 8 sub-chunks of the 32-chunks)
+    constexpr int PARTS = CK / 4;
+    constexpr int ROWV = KT * HH / 4;  // float4 per (tap, h) weight row
+    constexpr int SB = 8;              // staging batch (independent loads in flight per thread)
+    const int nx = tg.nslots * PARTS;
+    const int nw = g.ntaps * 2 * ROWV;
+    const int EHW = tg.EH * tg.EW;
+
+    const int cc_begin = (int)((long)split * nch / S), cc_end = (int)((long)(split + 1) * nch / S);
+    for (int cc = cc_begin; cc < cc_end; cc++) {
+        __syncthreads();
+        const int c0 = L32 ? (cc >> 2) * 32 : cc * CK;
+        const int sc = L32 ? (cc & 3) : 0;
+        const float *src;
+        int Cs, cofs;
+        if (c0 < g.C1) {
+            src = a1; Cs = g.C1; cofs = c0;
+        } else {
+            src = a2; Cs = g.C2; cofs = c0 - g.C1;
+        }
+        // staging in batches of SB independent 16-byte loads per thread (all issued before the first LDS write)
+        for (int base = 0; base < ((tg.dbg & 1) ? 0 : nx); base += SB * 256) {
+            float4 v[SB];
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int idx = base + u * 256 + tid;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < nx) {
+                    const int slot = idx / PARTS, part = idx - slot * PARTS;
+                    const int ez = slot / EHW, rem = slot - ez * EHW;
+                    const int ey = rem / tg.EW, ex = rem - ey * tg.EW;
+                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
+                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        v[u] = *reinterpret_cast<const float4 *>(
+                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs +
+                            (L32 ? part * 16 + sc * 4 : part * 4));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int idx = base + u * 256 + tid;
+                if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)idx * 4) = v[u];  // slot*CK + part*4 == idx*4
+            }
+        }
+        for (int base = 0; base < ((tg.dbg & 1) ? 0 : nw); base += SB * 256) {
+            float4 v[SB];
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int idx = base + u * 256 + tid;
+                if (idx < nw) {
+                    const int row = idx / ROWV, j = idx - row * ROWV;
+                    const int t = row >> 1, hh = row & 1;
+                    if (L32)  // HH == 4: one float4 per output channel j, strided by the 16-float k rows of the CK=32 layout
+                        v[u] = *reinterpret_cast<const float4 *>(
+                            w + ((((size_t)(cc >> 2) * g.T + wts[t]) * 2 + hh) * tg.K + (size_t)kb * KT + j) * 16 + sc * 4);
+                    else
+                        v[u] = *reinterpret_cast<const float4 *>(
+                            w + ((((size_t)cc * g.T + wts[t]) * 2 + hh) * tg.K + (size_t)kb * KT) * HH + j * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const int idx = base + u * 256 + tid;
+                if (idx < nw) *reinterpret_cast<float4 *>(Ws + (size_t)idx * 4) = v[u];  // row*KT*HH + j*4 == idx*4
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < ((tg.dbg & 2) ? 0 : g.ntaps); t++) {
+            const int to = tapoff[t];
+            float af[MT][HH], bf[NT][HH];
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const float *pa = Xs + (size_t)(sbase[m] + to) * CK + h * HH;
+                if (CK == 8) {
+                    float4 q = *reinterpret_cast<const float4 *>(pa);
+                    af[m][0] = q.x; af[m][1] = q.y; af[m][HH - 2] = q.z; af[m][HH - 1] = q.w;
+                } else {
+                    float2 q = *reinterpret_cast<const float2 *>(pa);
+                    af[m][0] = q.x; af[m][1] = q.y;
+                }
+            }
+#pragma unroll
+            for (int q_ = 0; q_ < NT; q_++) {
+                const float *pb = Ws + ((size_t)(t * 2 + h) * KT + q_ * 32 + i) * HH;
+                if (CK == 8) {
+                    float4 q = *reinterpret_cast<const float4 *>(pb);
+                    bf[q_][0] = q.x; bf[q_][1] = q.y; bf[q_][HH - 2] = q.z; bf[q_][HH - 1] = q.w;
+                } else {
+                    float2 q = *reinterpret_cast<const float2 *>(pb);
+                    bf[q_][0] = q.x; bf[q_][1] = q.y;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < HH; e++)
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int q_ = 0; q_ < NT; q_++)
+                        acc[m][q_] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][e], bf[q_][e], acc[m][q_], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (voxel of the 32-row M tile)
+    const int od = od0 + wave;
+    if (od >= g.Do) return;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q_ = 0; q_ < NT; q_++) {
+            const int k = kb * KT + q_ * 32 + i;
+            const float bv = (bias && S == 1) ? bias[k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int oh = oh0 + 4 * m + (row >> 3), ow = ow0 + (row & 7);
+                if (oh < g.Ho && ow < g.Wo) {
+                    if (S > 1) {  // raw partial, indexed by the iteration voxel: part[split][n][o][K]
+                        const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
+                        part[(((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k] = acc[m][q_][r];
+                        continue;
+                    }
+                    const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                                      (ow * g.so[2] + g.oo[2]);
+                    const float val = acc[m][q_][r] + bv;
+                    if (k < g.K1)
+                        y1[ov * g.K1 + k] = val;
+                    else
+                        y2[ov * g.K2 + (k - g.K1)] = val;
+                }
+            }
+        }
+}
+
+static const size_t LDS_LIMIT = 160 * 1024;
+static const int MAX_SPLIT = 16;
+
+// y[mapped(n,o)][k] = bias[k] + sum_s part[s][n][o][k]   (fixed order)
+__global__ void k_split_reduce(const FwdGeom g, const float *__restrict__ part, const float *__restrict__ bias,
+                               float *__restrict__ y1, float *__restrict__ y2, int S) {
+    const int K = g.K1 + g.K2;
+    const size_t per = (size_t)g.N * g.Do * g.Ho * g.Wo * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
+        float s = bias ? bias[idx % K] : 0.f;
+        for (int j = 0; j < S; j++) s += part[(size_t)j * per + idx];
+        const int k = (int)(idx % K);
+        size_t r = idx / K;
+        const int ow = (int)(r % g.Wo);
+        r /= g.Wo;
+        const int oh = (int)(r % g.Ho);
+        r /= g.Ho;
+        const int od = (int)(r % g.Do);
+        const int n = (int)(r / g.Do);
+        const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                          (ow * g.so[2] + g.oo[2]);
+        if (k < g.K1)
+            y1[ov * g.K1 + k] = s;
+        else
+            y2[ov * g.K2 + (k - g.K1)] = s;
+    }
+}
+
+size_t fwd_mfma_ws(int N, long out_vox, int K) {
+    // only skinny problems split: at most 64 tiles of 128 voxels per sample
+    if (out_vox > 64 * 128) return 0;
+    return (size_t)MAX_SPLIT * N * out_vox * K * sizeof(float) + 256;
+}
+
+// ------------------------------------------------------------------------------------------------ CK = 32 kernel
+// Stride-1 gathers with C % 32 == 0 (every 3x3x3 conv fwd / dgrad of the net but the strided ones).
+//   * workgroup = 4 waves = a 4 x (4*MT) x 8 voxel tile x 32*NT output channels;
+//   * per 32-channel chunk the whole halo tile [slots][32 ch] -- each voxel one full 128-byte line, padded to 36
+//     floats against LDS bank conflicts -- is staged ONCE (the 8-channel chunks of k_fwd_mfma re-fetch every line four
+//     times and go HBM-bound);
+//   * weights stream through a double-buffered LDS ring in groups of TG taps; the next group is prefetched into
+//     registers while the current group's MFMAs run (one barrier per group);
+//   * work items are dealt to workgroups in an XCD-contiguous order so that neighbouring tiles (shared halos) and the
+//     k-blocks of one tile meet in one XCD's L2.
+struct Fwd32Tile {
+    int EH, EW, nslots;
+    int min_off[3];
+    int ntd, nth, ntw, nkb, S;
+    int nitems;
+    int K;
+    int toff[27];
+    int dbg;
+};
+
+template <int NT, int MT, int TG>
+__global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Tile tg, const float *__restrict__ a1,
+                                                  const float *__restrict__ a2, const float *__restrict__ w,
+                                                  const float *__restrict__ bias, float *__restrict__ y1,
+                                                  float *__restrict__ y2, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KT = 32 * NT;
+    constexpr int XS = 36;                       // floats per halo slot (32 + 4 pad)
+    constexpr int WS = 20;                       // floats per (tap, h, k) weight row (16 + 4 pad)
+    constexpr int XR = MT == 2 ? 19 : 12;        // float4 per thread: 608 / 384 slots x 8
+    constexpr int XB = MT == 2 ? 10 : 12;        // staging batch (loads in flight per thread)
+    constexpr int WR = TG * 2 * KT * 4 / 256;    // float4 per thread per weight group
+    constexpr int WBUF = TG * 2 * KT * WS;       // floats per weight buffer
+    static_assert(TG * 2 * KT * 4 % 256 == 0, "weight group must be a multiple of 256 float4");
+    float *Xs = lds;
+    float *Wsm = lds + (size_t)XR * 32 * XS;     // halo buffer sized for XR*32 >= nslots slots
+    int *tapoff = reinterpret_cast<int *>(Wsm + 2 * WBUF);
+    int *wts = tapoff + 32;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 27; t++)
+        if (tid == t && t < g.ntaps) {
+            tapoff[t] = tg.toff[t];
+            wts[t] = g.wt[t];
+        }
+    // XCD-contiguous item order (blocks b and b+8 share an XCD): block b takes item (b%8)*ceil(n/8) + b/8
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= tg.nitems) return;  // whole workgroup
+    unsigned r_ = (unsigned)item;
+    const int kb = (int)(r_ % (unsigned)tg.nkb); r_ /= (unsigned)tg.nkb;
+    const int split = (int)(r_ % (unsigned)tg.S); r_ /= (unsigned)tg.S;
+    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+    const int td_ = (int)(r_ % (unsigned)tg.ntd);
+    const int n = (int)(r_ / (unsigned)tg.ntd);
+
+    const int C = g.C1 + g.C2;
+    const int nch = C / 32;
+    const int ngroups = (g.ntaps + TG - 1) / TG;
+    const int EHW = tg.EH * tg.EW;
+    const int nx = tg.nslots * 8;
+    const int od0 = td_ * 4, oh0 = th_ * (4 * MT), ow0 = tw_ * 8;
+    const int iz0 = od0 + tg.min_off[0], iy0 = oh0 + tg.min_off[1], ix0 = ow0 + tg.min_off[2];
+
+    int sbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) sbase[m] = ((wave * tg.EH) + 4 * m + (i >> 3)) * tg.EW + (i & 7);
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][q][r] = 0.f;
+
+    float4 wr[WR];
+    // weight group `gidx` of chunk `cc` -> registers.  idx = u*256 + tid = ((tl*2+hh)*KT + k)*4 + e4: with 256
+    // threads the tap of slot u is a compile-time function of u (block-uniform condition, no lane mask)
+    auto load_w = [&](int cc, int gidx) {
+#pragma unroll
+        for (int u = 0; u < WR; u++) {
+            const int idx = u * 256 + tid;
+            const int e4 = idx & 3, k = (idx >> 2) % KT;
+            const int tl = (NT == 1) ? u : (u >> 1);
+            const int hh = (NT == 1) ? (tid >> 7) : (u & 1);
+            const int t = gidx * TG + tl;
+            wr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < g.ntaps && !(tg.dbg & 1))
+                wr[u] = *reinterpret_cast<const float4 *>(
+                    w + ((((size_t)cc * g.T + wts[t]) * 2 + hh) * tg.K + (size_t)kb * KT + k) * 16 + e4 * 4);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < WR; u++) {
+            const int idx = u * 256 + tid;
+            *reinterpret_cast<float4 *>(Wsm + (size_t)buf * WBUF + (size_t)(idx >> 2) * WS + (idx & 3) * 4) = wr[u];
+        }
+    };
+
+    const int cc_begin = split * nch / tg.S, cc_end = (split + 1) * nch / tg.S;
+    __syncthreads();  // tapoff / wts visible
+    for (int cc = cc_begin; cc < cc_end; cc++) {
+        const int c0 = cc * 32;
+        const float *src;
+        int Cs, cofs;
+        if (c0 < g.C1) {
+            src = a1; Cs = g.C1; cofs = c0;
+        } else {
+            src = a2; Cs = g.C2; cofs = c0 - g.C1;
+        }
+        load_w(cc, 0);
+        __syncthreads();  // B1: every wave is done with the previous chunk's LDS
+        for (int base = 0; base < XR; base += XB) {
+            float4 v[XB];
+#pragma unroll
+            for (int u = 0; u < XB; u++) {
+                const int idx = (base + u) * 256 + tid;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (base + u < XR && idx < nx && !(tg.dbg & 1)) {
+                    const int slot = idx >> 3;
+                    const int ez = slot / EHW, rem = slot - ez * EHW;
+                    const int ey = rem / tg.EW, ex = rem - ey * tg.EW;
+                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
+                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        v[u] = *reinterpret_cast<const float4 *>(
+                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid & 7) * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < XB; u++) {
+                const int idx = (base + u) * 256 + tid;
+                if (base + u < XR) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * XS + (idx & 7) * 4) = v[u];
+            }
+        }
+        for (int gi = 0; gi < ngroups; gi++) {
+            store_w(gi & 1);
+            __syncthreads();  // B2: halo tile (gi == 0) and weight group gi visible; group gi-2's buffer is free
+            if (gi + 1 < ngroups) load_w(cc, gi + 1);  // in flight during this group's MFMAs
+            if (!(tg.dbg & 2)) {
+                const float *wb_ = Wsm + (size_t)(gi & 1) * WBUF;
+#pragma unroll
+                for (int tl = 0; tl < TG; tl++) {
+                    const int t = gi * TG + tl;
+                    if (t < g.ntaps) {  // block-uniform
+                        const int to = tapoff[t];
+                        float4 af[MT][4], bf[NT][4];
+#pragma unroll
+                        for (int m = 0; m < MT; m++) {
+                            const float4 *pa = reinterpret_cast<const float4 *>(Xs + (size_t)(sbase[m] + to) * XS + h * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) af[m][e] = pa[e];
+                        }
+#pragma unroll
+                        for (int q = 0; q < NT; q++) {
+                            const float4 *pb = reinterpret_cast<const float4 *>(wb_ + ((size_t)(tl * 2 + h) * KT + q * 32 + i) * WS);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) bf[q][e] = pb[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+#pragma unroll
+                            for (int c4 = 0; c4 < 4; c4++)
+#pragma unroll
+                                for (int m = 0; m < MT; m++)
+#pragma unroll
+                                    for (int q = 0; q < NT; q++) {
+                                        const float avv = c4 == 0 ? af[m][e].x : (c4 == 1 ? af[m][e].y : (c4 == 2 ? af[m][e].z : af[m][e].w));
+                                        const float bvv = c4 == 0 ? bf[q][e].x : (c4 == 1 ? bf[q][e].y : (c4 == 2 ? bf[q][e].z : bf[q][e].w));
+                                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv, bvv, acc[m][q], 0, 0, 0);
+                                    }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // epilogue
+    const int od = od0 + wave;
+    if (od >= g.Do) return;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            const int k = kb * KT + q * 32 + i;
+            const float bv = (bias && tg.S == 1) ? bias[k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int oh = oh0 + 4 * m + (row >> 3), ow = ow0 + (row & 7);
+                if (oh < g.Ho && ow < g.Wo) {
+                    if (tg.S > 1) {
+                        const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
+                        part[(((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k] = acc[m][q][r];
+                    } else {
+                        const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                                          (ow * g.so[2] + g.oo[2]);
+                        const float val = acc[m][q][r] + bv;
+                        if (k < g.K1)
+                            y1[ov * g.K1 + k] = val;
+                        else
+                            y2[ov * g.K2 + (k - g.K1)] = val;
+                    }
+                }
+            }
+        }
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+static int split_for(const void *ws, size_t ws_bytes, long wgs, int nch, size_t out_elems, int nkb) {
+    int S = 1;
+    if (ws && wgs < 256 && nch >= 4) {
+        long want = (512 + wgs - 1) / wgs;
+        if (want > MAX_SPLIT) want = MAX_SPLIT;
+        if (want > nch / 2) want = nch / 2;
+        while (want > 1 && (size_t)want * out_elems * sizeof(float) > ws_bytes) want--;
+        if (want > 1 && (long)nkb * want <= 65535) S = (int)want;
+    }
+    return S;
+}
+
+static int run_split_reduce(const FwdGeom &g, const float *part, const float *bias, float *y1, float *y2, int S,
+                            size_t out_elems, hipStream_t s) {
+    long blocks = cdiv((long)out_elems, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_split_reduce, dim3(blocks), dim3(256), 0, s, g, part, bias, y1, y2, S);
+    return check_launch("conv fwd split reduce");
+}
+
+template <int NT, int MT, int TG>
+static int launch_fwd32(const FwdGeom &g, Fwd32Tile &tg, const float *a1, const float *a2, const float *w,
+                        const float *bias, float *y1, float *y2, void *ws, size_t ws_bytes, hipStream_t s) {
+    auto kern = k_fwd32<NT, MT, TG>;
+    constexpr int XR = MT == 2 ? 19 : 12;
+    const size_t lds = ((size_t)XR * 32 * 36 + 2 * (size_t)TG * 2 * (32 * NT) * 20) * 4 + 64 * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS_LIMIT) != hipSuccess) {
+            set_error("conv fwd32 (mfma): cannot raise the dynamic LDS limit");
+            return 1;
+        }
+        configured = true;
+    }
+    const int K = g.K1 + g.K2;
+    tg.nkb = K / (32 * NT);
+    const long tiles = (long)tg.ntd * tg.nth * tg.ntw;
+    const size_t out_elems = (size_t)g.N * g.Do * g.Ho * g.Wo * K;
+    tg.S = split_for(ws, ws_bytes, tiles * tg.nkb * g.N, (g.C1 + g.C2) / 32, out_elems, tg.nkb);
+    const long nitems = tiles * tg.nkb * tg.S * g.N;
+    if (nitems > (1L << 30)) return -1;
+    tg.nitems = (int)nitems;
+    const long grid = ((nitems + 7) / 8) * 8;
+    float *part = reinterpret_cast<float *>(ws);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, g, tg, a1, a2, w, bias, y1, y2, part);
+    if (check_launch("conv fwd32 (mfma)")) return 1;
+    if (tg.S > 1) return run_split_reduce(g, part, bias, y1, y2, tg.S, out_elems, s);
+    return 0;
+}
+
+template <int CK, int NT, int MT, bool L32>
+static int launch_fwd(const FwdGeom &g, FwdTile &tg, size_t lds, const float *a1, const float *a2, const float *w,
+                      const float *bias, float *y1, float *y2, void *ws, size_t ws_bytes, hipStream_t s) {
+    auto kern = k_fwd_mfma<CK, NT, MT, L32>;
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS_LIMIT) != hipSuccess) {
+            set_error("conv fwd (mfma): cannot raise the dynamic LDS limit");
+            return 1;
+        }
+        configured = LDS_LIMIT;
+    }
+    const int K = g.K1 + g.K2;
+    const int nkb = K / (32 * NT);
+    const long tiles = (long)tg.ntd * tg.nth * tg.ntw;
+    const size_t out_elems = (size_t)g.N * g.Do * g.Ho * g.Wo * K;
+    // split the reduce chunks when the launch cannot fill the chip (8^3 / 4^3 stages with 320-640 channels)
+    const int S = split_for(ws, ws_bytes, tiles * nkb * g.N, (g.C1 + g.C2) / CK, out_elems, nkb);
+    dim3 grid((unsigned)tiles, nkb * S, g.N);
+    float *part = reinterpret_cast<float *>(ws);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tg, a1, a2, w, bias, y1, y2, S, part);
+    if (check_launch("conv fwd (mfma)")) return 1;
+    if (S > 1) return run_split_reduce(g, part, bias, y1, y2, S, out_elems, s);
+    return 0;
+}
+
+int fwd_mfma(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1, float *y2,
+             void *ws, size_t ws_bytes, hipStream_t s) {
+    const int C = g.C1 + g.C2, K = g.K1 + g.K2;
+    const int LCK = wl_ck(C);  // chunk size of the packed weight layout
+    if (LCK == 0 || g.ntaps < 1 || g.ntaps > 27) return -1;
+    if (g.C1 % LCK != 0 || g.C2 % LCK != 0) return -1;          // a chunk must not straddle the two input pointers
+    if (K % 32 != 0 || g.K1 % 32 != 0 || g.K2 % 32 != 0) return -1;  // nor a 32-wide N tile the two outputs
+    if (g.N > 65535 || K / 32 > 65535) return -1;
+    if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)w) & 15) return -1;
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("MVD_CONV_DBG") ? atoi(getenv("MVD_CONV_DBG")) : 0;
+    int mn[3] = {127, 127, 127}, mx[3] = {-127, -127, -127};
+    for (int t = 0; t < g.ntaps; t++)
+        for (int a = 0; a < 3; a++) {
+            if (g.off[t][a] < mn[a]) mn[a] = g.off[t][a];
+            if (g.off[t][a] > mx[a]) mx[a] = g.off[t][a];
+        }
+    const bool unit_stride = g.sa[0] == 1 && g.sa[1] == 1 && g.sa[2] == 1;
+    if (LCK == 32 && unit_stride && !(dbg & 4)) {
+        // ---- CK = 32 kernel: 4x8x8 tile (one workgroup per CU) or 4x4x8 tile (two per CU)
+        // a 64-wide N tile may span the two output pointers: each 32-wide half lies in one of them (K1 % 32 == 0)
+        const int NT = (K % 64 == 0) ? 2 : 1;
+        static int force_mt = -1;
+        if (force_mt < 0) force_mt = getenv("MVD_CONV_MT") ? atoi(getenv("MVD_CONV_MT")) : 0;
+        static int force_tg = -1;
+        if (force_tg < 0) force_tg = getenv("MVD_CONV_TG") ? atoi(getenv("MVD_CONV_TG")) : 0;
+        const int MT = force_mt ? force_mt : 1;
+        Fwd32Tile t32;
+        memset(&t32, 0, sizeof(t32));
+        t32.dbg = dbg;
+        const int T3[3] = {4, 4 * MT, 8};
+        int E[3];
+        for (int a = 0; a < 3; a++) {
+            E[a] = (T3[a] - 1) + (mx[a] - mn[a]) + 1;
+            t32.min_off[a] = mn[a];
+        }
+        t32.EH = E[1]; t32.EW = E[2];
+        t32.nslots = E[0] * E[1] * E[2];
+        if (t32.nslots <= (MT == 2 ? 19 : 12) * 32) {
+            for (int t = 0; t < g.ntaps; t++)
+                t32.toff[t] = ((g.off[t][0] - mn[0]) * t32.EH + (g.off[t][1] - mn[1])) * t32.EW + (g.off[t][2] - mn[2]);
+            t32.ntd = (g.Do + 3) / 4;
+            t32.nth = (g.Ho + 4 * MT - 1) / (4 * MT);
+            t32.ntw = (g.Wo + 7) / 8;
+            t32.K = K;
+            if (MT == 2) {
+                if (NT == 2) return launch_fwd32<2, 2, 3>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+                return launch_fwd32<1, 2, 3>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            }
+            if (NT == 2) return launch_fwd32<2, 1, 1>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            if (force_tg == 3) return launch_fwd32<1, 1, 3>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            return launch_fwd32<1, 1, 1>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+        }
+    }
+    // ---- chunked kernel (8- or 4-channel chunks; 8-channel sub-chunks of the 32-layout when LCK == 32)
+    const int CK = LCK == 32 ? 8 : LCK;
+    FwdTile tg;
+    memset(&tg, 0, sizeof(tg));
+    tg.dbg = dbg;
+    tg.K = K;
+    // candidate tile shapes, widest first
+    const int cand[3][2] = {{2, 2}, {2, 1}, {1, 1}};  // (MT, NT)
+    for (int ci = 0; ci < 3; ci++) {
+        const int MT = cand[ci][0], NT = cand[ci][1];
+        if (K % (32 * NT) != 0) continue;
+        const int T3[3] = {4, 4 * MT, 8};
+        int E[3];
+        for (int a = 0; a < 3; a++) {
+            E[a] = (T3[a] - 1) * g.sa[a] + (mx[a] - mn[a]) + 1;
+            tg.min_off[a] = mn[a];
+        }
+        tg.ED = E[0]; tg.EH = E[1]; tg.EW = E[2];
+        tg.nslots = E[0] * E[1] * E[2];
+        const size_t lds = ((size_t)tg.nslots * CK + (size_t)g.ntaps * 2 * (32 * NT) * (CK / 2)) * 4 + 64 * 4;
+        // prefer configurations that leave room for >= 2 workgroups per CU; accept one per CU for the widest halos
+        const bool fits2 = lds <= LDS_LIMIT / 2;
+        const bool last = (ci == 2);
+        if (!fits2 && !(last && lds <= LDS_LIMIT)) {
+            if (!last) continue;
+            return -1;
+        }
+        for (int t = 0; t < g.ntaps; t++)
+            tg.toff[t] = ((g.off[t][0] - mn[0]) * tg.EH + (g.off[t][1] - mn[1])) * tg.EW + (g.off[t][2] - mn[2]);
+        tg.ntd = (g.Do + 3) / 4;
+        tg.nth = (g.Ho + 4 * MT - 1) / (4 * MT);
+        tg.ntw = (g.Wo + 7) / 8;
+#define MVD_FWD_DISPATCH(CKV, L32V)                                                                                      \
+    {                                                                                                                    \
+        if (MT == 2 && NT == 2) return launch_fwd<CKV, 2, 2, L32V>(g, tg, lds, a1, a2, w, bias, y1, y2, ws, ws_bytes, s); \
+        if (MT == 2 && NT == 1) return launch_fwd<CKV, 1, 2, L32V>(g, tg, lds, a1, a2, w, bias, y1, y2, ws, ws_bytes, s); \
+        return launch_fwd<CKV, 1, 1, L32V>(g, tg, lds, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);                         \
+    }
+        if (LCK == 32) MVD_FWD_DISPATCH(8, true)
+        else if (CK == 8) MVD_FWD_DISPATCH(8, false)
+        else MVD_FWD_DISPATCH(4, false)
+#undef MVD_FWD_DISPATCH
+    }
     return -1;
 }
-size_t wgrad_mfma_ws(const WgradGeom &) { return 0; }
-int wgrad_mfma(const WgradGeom &, const float *, const float *, const float *, float *, void *, size_t, hipStream_t) {
-    return -1;
+
+// ================================================================================================ wgrad
+struct WgTile {
+    int TD, TH, TW, lTH, lTW;
+    int EAh, EAw, nslotsA, minA[3];
+    int EBh, EBw, nslotsB, minB[3];
+    int ntd, nth, ntw, nsplit, nkb;
+    long ntiles;
+    int toffA[27], toffB[27];
+};
+
+template <int TPW>
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+                                                       const float *__restrict__ a2, const float *__restrict__ b,
+                                                       float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;
+    float *Bs = lds + (size_t)tg.nslotsA * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y / tg.nkb, kb = blockIdx.y % tg.nkb;
+    const int split = blockIdx.x;
+    const int C = g.C1 + g.C2, K = g.K;
+
+    int ta[TPW], tb[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        ta[j] = tb[j] = 0;
+#pragma unroll
+        for (int t = 0; t < 27; t++)
+            if (t == wave + 4 * j && t < g.ntaps) {
+                ta[j] = tg.toffA[t];
+                tb[j] = tg.toffB[t];
+            }
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    // channel block -> source pointer (a 32-block never straddles the two inputs: host checks C1 % 32 == 0 if C2 > 0)
+    const int c0 = cb * 32;
+    const float *asrc;
+    int Cs, cofs;
+    if (c0 < g.C1) {
+        asrc = a1; Cs = g.C1; cofs = c0;
+    } else {
+        asrc = a2; Cs = g.C2; cofs = c0 - g.C1;
+    }
+    const int cvalid = (Cs - cofs) < 32 ? (Cs - cofs) : 32;  // partial block (e.g. the 4-channel input layer)
+    const int k0 = kb * 32;
+    const int kvalid = (K - k0) < 32 ? (K - k0) : 32;
+    const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
+    const int TV = tg.TD * tg.TH * tg.TW;
+    constexpr int SB = 8;  // staging batch
+
+    for (long tile = split; tile < tg.ntiles; tile += tg.nsplit) {
+        long r_ = tile;
+        const int tw_ = (int)(r_ % tg.ntw);
+        r_ /= tg.ntw;
+        const int th_ = (int)(r_ % tg.nth);
+        r_ /= tg.nth;
+        const int td_ = (int)(r_ % tg.ntd);
+        const int n = (int)(r_ / tg.ntd);
+        const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
+        __syncthreads();
+        // staging: batches of SB independent 16-byte loads per thread, all issued before the first LDS write
+        {
+            const int z0 = od0 * g.sa[0] + tg.minA[0], y0 = oh0 * g.sa[1] + tg.minA[1], x0 = ow0 * g.sa[2] + tg.minA[2];
+            const int na = tg.nslotsA * 8;
+            for (int base = 0; base < na; base += SB * 256) {
+                float4 v[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int idx = base + u * 256 + tid;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < na) {
+                        const int slot = idx >> 3, part = idx & 7;
+                        const int ez = slot / EAhw, rem = slot - ez * EAhw;
+                        const int ey = rem / tg.EAw, ex = rem - ey * tg.EAw;
+                        const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                        if (part * 4 < cvalid && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                            v[u] = *reinterpret_cast<const float4 *>(
+                                asrc + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int idx = base + u * 256 + tid;
+                    if (idx < na) *reinterpret_cast<float4 *>(As + (size_t)idx * 4) = v[u];
+                }
+            }
+        }
+        {
+            const int z0 = od0 * g.sb[0] + tg.minB[0], y0 = oh0 * g.sb[1] + tg.minB[1], x0 = ow0 * g.sb[2] + tg.minB[2];
+            const int nb = tg.nslotsB * 8;
+            for (int base = 0; base < nb; base += SB * 256) {
+                float4 v[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int idx = base + u * 256 + tid;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < nb) {
+                        const int slot = idx >> 3, part = idx & 7;
+                        const int ez = slot / EBhw, rem = slot - ez * EBhw;
+                        const int ey = rem / tg.EBw, ex = rem - ey * tg.EBw;
+                        const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                        if (part * 4 < kvalid && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
+                            v[u] = *reinterpret_cast<const float4 *>(
+                                b + ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SB; u++) {
+                    const int idx = base + u * 256 + tid;
+                    if (idx < nb) *reinterpret_cast<float4 *>(Bs + (size_t)idx * 4) = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        // branch-free k loop (k = voxel pair); operands of step s+1 are read from LDS while the MFMAs of step s run
+        float av[TPW], bv[TPW];
+        {
+            const int v = h;
+            const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
+            const int sa_ = ((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2];
+            const int sb_ = ((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2];
+#pragma unroll
+            for (int j = 0; j < TPW; j++) {
+                av[j] = As[(size_t)(sa_ + ta[j]) * 32 + i];
+                bv[j] = Bs[(size_t)(sb_ + tb[j]) * 32 + i];
+            }
+        }
+        for (int s2 = 0; s2 < TV; s2 += 2) {
+            float an[TPW], bn[TPW];
+            {
+                const int v = (s2 + 2 < TV ? s2 + 2 : s2) + h;  // last iteration re-reads its own operands (harmless)
+                const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
+                const int sa_ = ((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2];
+                const int sb_ = ((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2];
+#pragma unroll
+                for (int j = 0; j < TPW; j++) {
+                    an[j] = As[(size_t)(sa_ + ta[j]) * 32 + i];
+                    bn[j] = Bs[(size_t)(sb_ + tb[j]) * 32 + i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPW; j++) {
+                av[j] = an[j];
+                bv[j] = bn[j];
+            }
+        }
+    }
+    // partial[split][t][c][k]; D layout: col = lane&31 -> k, row -> c
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        const int t = wave + 4 * j;
+        if (t < g.ntaps) {
+            float *po = partial + ((size_t)split * g.ntaps + t) * C * K;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < cvalid && i < kvalid) po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
+            }
+        }
+    }
 }
+
+// dw[torch layout] = sum_split partial[split][t][c][k]   (fp32 partials, fp64 sum, fixed order)
+__global__ void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial, float *__restrict__ dw, int nsplit) {
+    const int C = g.C1 + g.C2, K = g.K;
+    const long per = (long)g.ntaps * C * K;
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= per) return;
+    double s = 0;
+    for (int b = 0; b < nsplit; b++) s += (double)partial[(size_t)b * per + j];
+    const int k = (int)(j % K);
+    const int c = (int)((j / K) % C);
+    const int t = g.wt[(int)(j / ((long)K * C))];
+    size_t o = g.transposed_out ? ((size_t)c * K + k) * g.T + t : ((size_t)k * C + c) * g.T + t;
+    dw[o] = (float)s;
+}
+
+static int wgrad_max_split(const WgradGeom &g) {
+    const int C = g.C1 + g.C2;
+    const int ncb = (C + 31) / 32, nkb = (g.K + 31) / 32;
+    long ns = 1024 / ((long)ncb * nkb);
+    if (ns < 1) ns = 1;
+    const long per = (long)g.ntaps * C * g.K * 4;
+    long cap = (256L << 20) / per;
+    if (cap < 1) cap = 1;
+    if (ns > cap) ns = cap;
+    return (int)ns;
+}
+
+static bool wgrad_mfma_ok(const WgradGeom &g) {
+    const int C = g.C1 + g.C2;
+    if (g.ntaps < 1 || g.ntaps > 27) return false;
+    if (g.C1 % 4 != 0 || g.C2 % 4 != 0 || g.K % 4 != 0) return false;
+    if (g.C2 > 0 && g.C1 % 32 != 0) return false;
+    if (C < 4 || g.K < 4) return false;
+    return true;
+}
+
+size_t wgrad_mfma_ws(const WgradGeom &g) {
+    if (!wgrad_mfma_ok(g)) return 0;
+    return (size_t)wgrad_max_split(g) * g.ntaps * (g.C1 + g.C2) * g.K * sizeof(float) + 256;
+}
+
+int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
+               hipStream_t s) {
+    if (!wgrad_mfma_ok(g)) return -1;
+    if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)b) & 15) return -1;
+    const int C = g.C1 + g.C2;
+    WgTile tg;
+    memset(&tg, 0, sizeof(tg));
+    int mnA[3] = {127, 127, 127}, mxA[3] = {-127, -127, -127}, mnB[3] = {127, 127, 127}, mxB[3] = {-127, -127, -127};
+    for (int t = 0; t < g.ntaps; t++)
+        for (int a = 0; a < 3; a++) {
+            if (g.off[t][a] < mnA[a]) mnA[a] = g.off[t][a];
+            if (g.off[t][a] > mxA[a]) mxA[a] = g.off[t][a];
+            if (g.ob[t][a] < mnB[a]) mnB[a] = g.ob[t][a];
+            if (g.ob[t][a] > mxB[a]) mxB[a] = g.ob[t][a];
+        }
+    // tile shapes (powers of two), largest first; need LDS <= half the CU's so two workgroups co-reside
+    const int cand[4][3] = {{2, 8, 8}, {2, 4, 8}, {2, 4, 4}, {1, 4, 4}};
+    size_t lds = 0;
+    bool found = false;
+    for (int ci = 0; ci < 4 && !found; ci++) {
+        const int T3[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
+        int EA[3], EB[3];
+        for (int a = 0; a < 3; a++) {
+            EA[a] = (T3[a] - 1) * g.sa[a] + (mxA[a] - mnA[a]) + 1;
+            EB[a] = (T3[a] - 1) * g.sb[a] + (mxB[a] - mnB[a]) + 1;
+        }
+        const size_t need = ((size_t)EA[0] * EA[1] * EA[2] + (size_t)EB[0] * EB[1] * EB[2]) * 32 * 4;
+        if (need <= LDS_LIMIT / 2 || (ci == 3 && need <= LDS_LIMIT)) {
+            found = true;
+            lds = need;
+            tg.TD = T3[0]; tg.TH = T3[1]; tg.TW = T3[2];
+            tg.lTH = T3[1] == 8 ? 3 : 2;
+            tg.lTW = T3[2] == 8 ? 3 : 2;
+            tg.EAh = EA[1]; tg.EAw = EA[2]; tg.nslotsA = EA[0] * EA[1] * EA[2];
+            tg.EBh = EB[1]; tg.EBw = EB[2]; tg.nslotsB = EB[0] * EB[1] * EB[2];
+        }
+    }
+    if (!found) return -1;
+    for (int a = 0; a < 3; a++) {
+        tg.minA[a] = mnA[a];
+        tg.minB[a] = mnB[a];
+    }
+    for (int t = 0; t < g.ntaps; t++) {
+        tg.toffA[t] = ((g.off[t][0] - mnA[0]) * tg.EAh + (g.off[t][1] - mnA[1])) * tg.EAw + (g.off[t][2] - mnA[2]);
+        tg.toffB[t] = ((g.ob[t][0] - mnB[0]) * tg.EBh + (g.ob[t][1] - mnB[1])) * tg.EBw + (g.ob[t][2] - mnB[2]);
+    }
+    tg.ntd = (g.Do + tg.TD - 1) / tg.TD;
+    tg.nth = (g.Ho + tg.TH - 1) / tg.TH;
+    tg.ntw = (g.Wo + tg.TW - 1) / tg.TW;
+    tg.ntiles = (long)g.N * tg.ntd * tg.nth * tg.ntw;
+    const int ncb = (C + 31) / 32;
+    tg.nkb = (g.K + 31) / 32;
+    long ns = wgrad_max_split(g);
+    if (ns > tg.ntiles) ns = tg.ntiles;
+    tg.nsplit = (int)ns;
+    const size_t need_ws = (size_t)tg.nsplit * g.ntaps * C * g.K * sizeof(float);
+    if (ws_bytes < need_ws) {
+        set_error("conv wgrad (mfma): workspace too small (%zu < %zu)", ws_bytes, need_ws);
+        return 1;
+    }
+    if ((long)ncb * tg.nkb > 65535) return -1;
+    float *partial = reinterpret_cast<float *>(ws);
+    const int tpw = (g.ntaps + 3) / 4;
+    dim3 grid(tg.nsplit, ncb * tg.nkb);
+#define WG_LAUNCH(TPW)                                                                                             \
+    {                                                                                                              \
+        auto kern = k_wgrad_mfma<TPW>;                                                                             \
+        static bool cfgd = false;                                                                                  \
+        if (!cfgd && lds > 64 * 1024) {                                                                            \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)LDS_LIMIT) != hipSuccess) {                                               \
+                set_error("conv wgrad (mfma): cannot raise the dynamic LDS limit");                                \
+                return 1;                                                                                          \
+            }                                                                                                      \
+            cfgd = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tg, a1, a2, b, partial);                              \
+    }
+    if (tpw <= 1) WG_LAUNCH(1)
+    else if (tpw == 2) WG_LAUNCH(2)
+    else if (tpw <= 4) WG_LAUNCH(4)
+    else WG_LAUNCH(7)
+#undef WG_LAUNCH
+    if (check_launch("conv wgrad (mfma)")) return 1;
+    const long per = (long)g.ntaps * C * g.K;
+    hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per, 256)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
+    return check_launch("conv wgrad reduce (mfma)");
+}
+
 }  // namespace mvd

@@ -86,15 +86,17 @@ __global__ void k_in_stats(const float *__restrict__ x, double *__restrict__ par
 
 __global__ void k_in_finalize(const double *__restrict__ partial, float *__restrict__ mean, float *__restrict__ rstd,
                               int C, int nblk, long V, float eps) {
-    int n = blockIdx.y;
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one wave per (n, c): lanes stride over the block partials, fixed shuffle tree (deterministic)
+    const int n = blockIdx.y, c = blockIdx.x;
     double a = 0, q = 0;
-    for (int b = 0; b < nblk; b++) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
         size_t o = (((size_t)n * nblk + b) * C + c) * 2;
         a += partial[o];
         q += partial[o + 1];
     }
+    a = wave_sum(a);
+    q = wave_sum(q);
+    if (threadIdx.x != 0) return;
     double m = a / (double)V;
     double var = q / (double)V - m * m;
     if (var < 0) var = 0;
@@ -199,23 +201,29 @@ __global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restr
 // sums[n][c][2] (float) = (sum dz, sum dz*xhat); dgamma/dbeta over n
 __global__ void k_in_bwd_finalize(const double *__restrict__ partial, float *__restrict__ sums,
                                   float *__restrict__ dgamma, float *__restrict__ dbeta, int N, int C, int nblk) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one wave per channel: lanes stride over the block partials of each sample, fixed shuffle tree
+    const int c = blockIdx.x;
     double tg = 0, tb = 0;
     for (int n = 0; n < N; n++) {
         double a = 0, q = 0;
-        for (int b = 0; b < nblk; b++) {
+        for (int b = threadIdx.x; b < nblk; b += 64) {
             size_t o = (((size_t)n * nblk + b) * C + c) * 2;
             a += partial[o];
             q += partial[o + 1];
         }
-        sums[((size_t)n * C + c) * 2 + 0] = (float)a;
-        sums[((size_t)n * C + c) * 2 + 1] = (float)q;
+        a = wave_sum(a);
+        q = wave_sum(q);
+        if (threadIdx.x == 0) {
+            sums[((size_t)n * C + c) * 2 + 0] = (float)a;
+            sums[((size_t)n * C + c) * 2 + 1] = (float)q;
+        }
         tb += a;
         tg += q;
     }
-    dgamma[c] = (float)tg;
-    dbeta[c] = (float)tb;
+    if (threadIdx.x == 0) {
+        dgamma[c] = (float)tg;
+        dbeta[c] = (float)tb;
+    }
 }
 
 template <int VEC>
@@ -287,7 +295,7 @@ int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta
     else
         hipLaunchKernelGGL(k_in_stats<1>, grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
     if (check_launch("instnorm stats")) return 1;
-    hipLaunchKernelGGL(k_in_finalize, dim3(cdiv(C, 64), N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
+    hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
     if (check_launch("instnorm finalize")) return 1;
     long per_n = V * C / (v4 ? 4 : 1);
     long bx = cdiv(per_n, 256);
@@ -321,7 +329,7 @@ int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, 
         hipLaunchKernelGGL(k_in_bwd_stats<1>, grid, dim3(g.threads), sm, s, x, dy, gamma, beta, mean, rstd, partial, C,
                            g.CG, g.R, V, g.chunk, slope);
     if (check_launch("instnorm bwd stats")) return 1;
-    hipLaunchKernelGGL(k_in_bwd_finalize, dim3(cdiv(C, 64)), dim3(64), 0, s, partial, sums, dgamma, dbeta, N, C,
+    hipLaunchKernelGGL(k_in_bwd_finalize, dim3(C), dim3(64), 0, s, partial, sums, dgamma, dbeta, N, C,
                        g.nblk);
     if (check_launch("instnorm bwd finalize")) return 1;
     long per_n = V * C / (v4 ? 4 : 1);

@@ -123,6 +123,56 @@ __global__ void k_seghead_dw(const float *__restrict__ x, const float *__restric
     }
 }
 
+// streaming variant for C % 4 == 0: thread = (4-channel group, row); each thread keeps K x 4 accumulators in
+// registers while walking its rows with float4 loads; rows are combined through LDS in a fixed order.
+__global__ void k_seghead_dw4(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
+                              int N, long V, int C, int K, long chunk) {
+    extern __shared__ float smf[];  // [R][K*C + K]
+    const int t = threadIdx.x;
+    const int CG = C / 4, R = blockDim.x / CG;
+    const int g = t % CG, r = t / CG;
+    const long total = (long)N * V;
+    const long g0 = (long)blockIdx.x * chunk;
+    long g1 = g0 + chunk;
+    if (g1 > total) g1 = total;
+    const int nv_out = K * C + K;
+    float acc[KMAX][4], accb[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        accb[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[k][j] = 0.f;
+    }
+    if (r < R) {
+        for (long i = g0 + r; i < g1; i += R) {
+            const long n = i / V, v = i - n * V;
+            const float4 q = *reinterpret_cast<const float4 *>(x + (size_t)i * C + g * 4);
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                if (k < K) {
+                    const float d = dl[((size_t)n * K + k) * V + v];
+                    acc[k][0] += d * q.x; acc[k][1] += d * q.y; acc[k][2] += d * q.z; acc[k][3] += d * q.w;
+                    accb[k] += d;
+                }
+        }
+        float *o = smf + (size_t)r * nv_out;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[k * C + g * 4 + j] = acc[k][j];
+                if (g == 0) o[K * C + k] = accb[k];
+            }
+    }
+    __syncthreads();
+    double *po = partial + (size_t)blockIdx.x * nv_out;
+    for (int j = t; j < nv_out; j += blockDim.x) {
+        double s = 0;
+        for (int rr = 0; rr < R; rr++) s += (double)smf[(size_t)rr * nv_out + j];
+        po[j] = s;
+    }
+}
+
 // =============================================================================================== DC + CE
 __device__ inline int label_of(float t, int K) {
     int y = (int)t;  // .long() truncation (robust_ce_loss.py:16)
@@ -501,7 +551,13 @@ int mvd_seghead_bwd(const float *x, const float *w, const float *dlogits, float 
         int nblk;
         long chunk = seghead_chunk((long)N * V, &nblk);
         double *partial = reinterpret_cast<double *>(ws);
-        hipLaunchKernelGGL(k_seghead_dw, dim3(nblk), dim3(256), 0, s, x, dlogits, partial, N, V, C, K, chunk);
+        const int CG = C / 4, R = (C % 4 == 0 && CG <= 256) ? 256 / CG : 0;
+        const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
+        if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0)
+            hipLaunchKernelGGL(k_seghead_dw4, dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s, x, dlogits, partial, N, V,
+                               C, K, chunk);
+        else
+            hipLaunchKernelGGL(k_seghead_dw, dim3(nblk), dim3(256), 0, s, x, dlogits, partial, N, V, C, K, chunk);
         if (check_launch("seghead_dw")) return 1;
         // outputs [K*C] then [K]: dw and dbias are separate buffers -> two reduces over the same partials
         if (reduce_partials(partial, dw, nblk, K * C, s, K * C + K, 0)) return 1;

@@ -125,8 +125,9 @@ class Conv3dFn(Function):
         wf, wb = pack_weight(weight, False)
         od = [_out_dim(i, k, s) for i, k, s in zip((D, H, W), ks, stride)]
         y = empty_cl3d((N, K, *od), x1.device)
+        ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, od[0] * od[1] * od[2], K), x1.device)
         call("mvd_conv3d_fwd", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
-             _stream())
+             _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x1, x2, wb)
         ctx.geom = (N, C1, C2, D, H, W, K, ks, tuple(stride), tuple(od), bias is not None)
         return y
@@ -143,8 +144,9 @@ class Conv3dFn(Function):
         if need1 or need2:
             dx1 = empty_cl3d((N, C1, D, H, W), dev)
             dx2 = empty_cl3d((N, C2, D, H, W), dev) if x2 is not None else None
+            ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C1 + C2), dev)
             call("mvd_conv3d_dgrad", _p(dy), _p(wb), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks), i3(stride),
-                 _stream())
+                 _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[2]:
             T = ks[0] * ks[1] * ks[2]
             dw = torch.empty((K, C1 + C2, *ks), dtype=torch.float32, device=dev)
@@ -171,7 +173,9 @@ class ConvTranspose3dFn(Function):
             raise RuntimeError("convT3d: channel mismatch")
         wf, wb = pack_weight(weight, True)
         y = empty_cl3d((N, K, D * stride[0], H * stride[1], W * stride[2]), x.device)
-        call("mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _stream())
+        ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K), x.device)
+        call("mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
+             _stream())
         ctx.save_for_backward(x, wb)
         ctx.geom = (N, C, K, D, H, W, tuple(stride), bias is not None)
         return y
@@ -186,7 +190,9 @@ class ConvTranspose3dFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = empty_cl3d((N, C, D, H, W), dev)
-            call("mvd_convT3d_dgrad", _p(dy), _p(wb), _p(dx), N, D, H, W, C, K, i3(stride), _stream())
+            ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C), dev)
+            call("mvd_convT3d_dgrad", _p(dy), _p(wb), _p(dx), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
+                 _stream())
         if ctx.needs_input_grad[1]:
             T = stride[0] * stride[1] * stride[2]
             dw = torch.empty((C, K, *stride), dtype=torch.float32, device=dev)
