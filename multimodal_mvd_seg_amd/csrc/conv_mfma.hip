@@ -259,6 +259,7 @@ size_t fwd_mfma_ws(int N, long out_vox, int K) {
 //     k-blocks of one tile meet in one XCD's L2.
 struct Fwd32Tile {
     int EH, EW, nslots;
+    int magW, magHW;  // 16-bit reciprocal multipliers for / EW and / (EH*EW) (host-verified on the slot range)
     int min_off[3];
     int ntd, nth, ntw, nkb, S;
     int nitems;
@@ -372,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (base + u < XR && idx < nx && !(tg.dbg & 1)) {
                     const int slot = idx >> 3;
-                    const int ez = slot / EHW, rem = slot - ez * EHW;
-                    const int ey = rem / tg.EW, ex = rem - ey * tg.EW;
+                    const int ez = (slot * tg.magHW) >> 16, rem = slot - ez * EHW;
+                    const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
                     const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
                     if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
                         v[u] = *reinterpret_cast<const float4 *>(
@@ -586,7 +587,15 @@ int fwd_mfma(const FwdGeom &g, const float *a1, const float *a2, const float *w,
         }
         t32.EH = E[1]; t32.EW = E[2];
         t32.nslots = E[0] * E[1] * E[2];
-        if (t32.nslots <= (MT == 2 ? 19 : 12) * 32) {
+        auto magic = [](int d, int nmax) -> int {
+            int m = (1 << 16) / d + 1;
+            for (int n = 0; n < nmax; n++)
+                if (((n * m) >> 16) != n / d) return -1;
+            return m;
+        };
+        t32.magHW = magic(t32.EH * t32.EW, t32.nslots);
+        t32.magW = magic(t32.EW, t32.EH * t32.EW);
+        if (t32.nslots <= (MT == 2 ? 19 : 12) * 32 && t32.magHW > 0 && t32.magW > 0) {
             for (int t = 0; t < g.ntaps; t++)
                 t32.toff[t] = ((g.off[t][0] - mn[0]) * t32.EH + (g.off[t][1] - mn[1])) * t32.EW + (g.off[t][2] - mn[2]);
             t32.ntd = (g.Do + 3) / 4;
@@ -599,7 +608,8 @@ int fwd_mfma(const FwdGeom &g, const float *a1, const float *a2, const float *w,
             }
             if (NT == 2) return launch_fwd32<2, 1, 1>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
             if (force_tg == 3) return launch_fwd32<1, 1, 3>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
-            return launch_fwd32<1, 1, 1>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            if (force_tg == 1) return launch_fwd32<1, 1, 1>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            return launch_fwd32<1, 1, 2>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
         }
     }
     // ---- chunked kernel (8- or 4-channel chunks; 8-channel sub-chunks of the 32-layout when LCK == 32)
@@ -653,18 +663,23 @@ struct WgTile {
     int TD, TH, TW, lTH, lTW;
     int EAh, EAw, nslotsA, minA[3];
     int EBh, EBw, nslotsB, minB[3];
+    int magAw, magAhw, magBw, magBhw;  // 16-bit reciprocal multipliers: q = (n * mag) >> 16 (exact, host-verified)
     int ntd, nth, ntw, nsplit, nkb;
-    long ntiles;
+    int ntiles;
     int toffA[27], toffB[27];
+    int dbg;
 };
 
-template <int TPW>
-__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+// NA / NB: float4 per thread of the A halo / B tile (LDS regions are NA*4 KiB and NB*4 KiB).  The NEXT tile's A and B
+// are prefetched into registers while the current tile's MFMAs run.
+// SH: 1 = every tap reads the same B slot (3x3x3 conv: B = dy), 2 = the same A slot (transposed conv), 0 = neither
+template <int TPW, int NA, int NB, int SH>
+__global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
                                                        const float *__restrict__ a2, const float *__restrict__ b,
                                                        float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;
-    float *Bs = lds + (size_t)tg.nslotsA * 32;
+    float *Bs = lds + (size_t)NA * 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -675,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const WgradGeom g, const 
     int ta[TPW], tb[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
-        ta[j] = tb[j] = 0;
+        ta[j] = tb[j] = 0;  // taps beyond ntaps alias tap offset 0: their MFMAs run (branch-free) and are discarded
 #pragma unroll
         for (int t = 0; t < 27; t++)
             if (t == wave + 4 * j && t < g.ntaps) {
@@ -703,106 +718,117 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(const WgradGeom g, const 
     const int kvalid = (K - k0) < 32 ? (K - k0) : 32;
     const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
     const int TV = tg.TD * tg.TH * tg.TW;
-    constexpr int SB = 8;  // staging batch
+    const int na = tg.nslotsA * 8, nb = tg.nslotsB * 8;
+    const int part = tid & 7;
+    const bool aok = part * 4 < cvalid, bok = part * 4 < kvalid;
 
-    for (long tile = split; tile < tg.ntiles; tile += tg.nsplit) {
-        long r_ = tile;
-        const int tw_ = (int)(r_ % tg.ntw);
-        r_ /= tg.ntw;
-        const int th_ = (int)(r_ % tg.nth);
-        r_ /= tg.nth;
-        const int td_ = (int)(r_ % tg.ntd);
-        const int n = (int)(r_ / tg.ntd);
+    float4 ra[NA], rb[NB];
+    auto load_tile = [&](int tile) {
+        unsigned r_ = (unsigned)tile;
+        const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+        const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+        const int td_ = (int)(r_ % (unsigned)tg.ntd);
+        const int n = (int)(r_ / (unsigned)tg.ntd);
         const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
-        __syncthreads();
-        // staging: batches of SB independent 16-byte loads per thread, all issued before the first LDS write
         {
             const int z0 = od0 * g.sa[0] + tg.minA[0], y0 = oh0 * g.sa[1] + tg.minA[1], x0 = ow0 * g.sa[2] + tg.minA[2];
-            const int na = tg.nslotsA * 8;
-            for (int base = 0; base < na; base += SB * 256) {
-                float4 v[SB];
 #pragma unroll
-                for (int u = 0; u < SB; u++) {
-                    const int idx = base + u * 256 + tid;
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (idx < na) {
-                        const int slot = idx >> 3, part = idx & 7;
-                        const int ez = slot / EAhw, rem = slot - ez * EAhw;
-                        const int ey = rem / tg.EAw, ex = rem - ey * tg.EAw;
-                        const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
-                        if (part * 4 < cvalid && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
-                            v[u] = *reinterpret_cast<const float4 *>(
-                                asrc + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SB; u++) {
-                    const int idx = base + u * 256 + tid;
-                    if (idx < na) *reinterpret_cast<float4 *>(As + (size_t)idx * 4) = v[u];
-                }
+            for (int u = 0; u < NA; u++) {
+                const int idx = u * 256 + tid;
+                const int slot = idx >> 3;
+                const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
+                const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
+                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (aok && idx < na && !(tg.dbg & 1) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                    ra[u] = *reinterpret_cast<const float4 *>(
+                        asrc + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 4);
             }
         }
         {
             const int z0 = od0 * g.sb[0] + tg.minB[0], y0 = oh0 * g.sb[1] + tg.minB[1], x0 = ow0 * g.sb[2] + tg.minB[2];
-            const int nb = tg.nslotsB * 8;
-            for (int base = 0; base < nb; base += SB * 256) {
-                float4 v[SB];
 #pragma unroll
-                for (int u = 0; u < SB; u++) {
-                    const int idx = base + u * 256 + tid;
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (idx < nb) {
-                        const int slot = idx >> 3, part = idx & 7;
-                        const int ez = slot / EBhw, rem = slot - ez * EBhw;
-                        const int ey = rem / tg.EBw, ex = rem - ey * tg.EBw;
-                        const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
-                        if (part * 4 < kvalid && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
-                            v[u] = *reinterpret_cast<const float4 *>(
-                                b + ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < SB; u++) {
-                    const int idx = base + u * 256 + tid;
-                    if (idx < nb) *reinterpret_cast<float4 *>(Bs + (size_t)idx * 4) = v[u];
-                }
+            for (int u = 0; u < NB; u++) {
+                const int idx = u * 256 + tid;
+                const int slot = idx >> 3;
+                const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
+                const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
+                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bok && idx < nb && !(tg.dbg & 1) && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
+                    rb[u] = *reinterpret_cast<const float4 *>(
+                        b + ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 4);
             }
         }
+    };
+    auto store_tile = [&]() {  // unconditional: the LDS regions hold NA*256 / NB*256 float4
+#pragma unroll
+        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 256 + tid) * 4) = ra[u];
+#pragma unroll
+        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 256 + tid) * 4) = rb[u];
+    };
+    // operands of k-step s2 (k = voxel pair).  Byte offsets: slot*128 + lane column; the per-tap part is hoisted.
+    int aoff[TPW], boff[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        aoff[j] = ta[j] * 128 + i * 4;
+        boff[j] = tb[j] * 128 + i * 4;
+    }
+    const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
+    constexpr int NAV = SH == 2 ? 1 : TPW, NBV = SH == 1 ? 1 : TPW;
+    auto read_ops = [&](int s2, float (&av)[NAV], float (&bv)[NBV]) {
+        const int v = (s2 < TV ? s2 : TV - 2) + h;  // the tail prefetch re-reads the last step (harmless)
+        const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
+        const int sa_ = (((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2]) * 128;
+        const int sb_ = (((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2]) * 128;
+#pragma unroll
+        for (int j = 0; j < NAV; j++) av[j] = *reinterpret_cast<const float *>(Ab + sa_ + aoff[j]);
+#pragma unroll
+        for (int j = 0; j < NBV; j++) bv[j] = *reinterpret_cast<const float *>(Bb + sb_ + boff[j]);
+    };
+    auto mfmas = [&](const float (&av)[NAV], const float (&bv)[NBV]) {
+#pragma unroll
+        for (int j = 0; j < TPW; j++)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[SH == 2 ? 0 : j], bv[SH == 1 ? 0 : j], acc[j], 0, 0, 0);
+    };
+    // scheduling hint for one (reads of the next step | MFMAs of this step) block: one MFMA, then a few of the
+    // next step's LDS reads / address VALU ops under its shadow
+    auto interleave = [&]() {
+#pragma unroll
+        for (int j = 0; j < TPW; j++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+        }
+    };
+
+    int tile = split;
+    if (tile < tg.ntiles) load_tile(tile);
+    while (tile < tg.ntiles) {
+        __syncthreads();  // every wave is done reading the previous tile
+        store_tile();
         __syncthreads();
-        // branch-free k loop (k = voxel pair); operands of step s+1 are read from LDS while the MFMAs of step s run
-        float av[TPW], bv[TPW];
-        {
-            const int v = h;
-            const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
-            const int sa_ = ((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2];
-            const int sb_ = ((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2];
-#pragma unroll
-            for (int j = 0; j < TPW; j++) {
-                av[j] = As[(size_t)(sa_ + ta[j]) * 32 + i];
-                bv[j] = Bs[(size_t)(sb_ + tb[j]) * 32 + i];
+        const int next = tile + tg.nsplit;
+        if (next < tg.ntiles) load_tile(next);  // in flight during this tile's MFMAs
+        // branch-free k loop unrolled by two with ping-pong operand registers: the LDS reads of step s+1 are issued
+        // under the MFMAs of step s (left alone, the scheduler sinks every read next to its MFMA and each MFMA then
+        // eats a full LDS round trip)
+        if (!(tg.dbg & 2)) {
+            float a0[NAV], b0[NBV], a1_[NAV], b1_[NBV];
+            read_ops(0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int s2 = 0; s2 < TV; s2 += 4) {  // TV is a multiple of 4 for every tile shape
+                read_ops(s2 + 2, a1_, b1_);
+                mfmas(a0, b0);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                read_ops(s2 + 4, a0, b0);
+                mfmas(a1_, b1_);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        for (int s2 = 0; s2 < TV; s2 += 2) {
-            float an[TPW], bn[TPW];
-            {
-                const int v = (s2 + 2 < TV ? s2 + 2 : s2) + h;  // last iteration re-reads its own operands (harmless)
-                const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
-                const int sa_ = ((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2];
-                const int sb_ = ((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2];
-#pragma unroll
-                for (int j = 0; j < TPW; j++) {
-                    an[j] = As[(size_t)(sa_ + ta[j]) * 32 + i];
-                    bn[j] = Bs[(size_t)(sb_ + tb[j]) * 32 + i];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TPW; j++) {
-                av[j] = an[j];
-                bv[j] = bn[j];
-            }
-        }
+        tile = next;
     }
     // partial[split][t][c][k]; D layout: col = lane&31 -> k, row -> c
 #pragma unroll
@@ -837,7 +863,7 @@ __global__ void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial,
 static int wgrad_max_split(const WgradGeom &g) {
     const int C = g.C1 + g.C2;
     const int ncb = (C + 31) / 32, nkb = (g.K + 31) / 32;
-    long ns = 1024 / ((long)ncb * nkb);
+    long ns = 256 / ((long)ncb * nkb);  // one workgroup per CU (register budget of the prefetching kernel)
     if (ns < 1) ns = 1;
     const long per = (long)g.ntaps * C * g.K * 4;
     long cap = (256L << 20) / per;
@@ -867,6 +893,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     const int C = g.C1 + g.C2;
     WgTile tg;
     memset(&tg, 0, sizeof(tg));
+    tg.dbg = getenv("MVD_CONV_DBG") ? atoi(getenv("MVD_CONV_DBG")) : 0;
     int mnA[3] = {127, 127, 127}, mxA[3] = {-127, -127, -127}, mnB[3] = {127, 127, 127}, mxB[3] = {-127, -127, -127};
     for (int t = 0; t < g.ntaps; t++)
         for (int a = 0; a < 3; a++) {
@@ -875,29 +902,43 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
             if (g.ob[t][a] < mnB[a]) mnB[a] = g.ob[t][a];
             if (g.ob[t][a] > mxB[a]) mxB[a] = g.ob[t][a];
         }
-    // tile shapes (powers of two), largest first; need LDS <= half the CU's so two workgroups co-reside
+    // tile shapes (powers of two), largest first.  Two register/LDS configurations: (NA, NB) = (13, 4) for halo-heavy
+    // A (3x3x3 convs) and (2, 16) for halo-heavy B (transposed convs); both leave room for two workgroups per CU.
     const int cand[4][3] = {{2, 8, 8}, {2, 4, 8}, {2, 4, 4}, {1, 4, 4}};
-    size_t lds = 0;
-    bool found = false;
-    for (int ci = 0; ci < 4 && !found; ci++) {
+    int cfg = -1;
+    for (int ci = 0; ci < 4 && cfg < 0; ci++) {
         const int T3[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
         int EA[3], EB[3];
         for (int a = 0; a < 3; a++) {
             EA[a] = (T3[a] - 1) * g.sa[a] + (mxA[a] - mnA[a]) + 1;
             EB[a] = (T3[a] - 1) * g.sb[a] + (mxB[a] - mnB[a]) + 1;
         }
-        const size_t need = ((size_t)EA[0] * EA[1] * EA[2] + (size_t)EB[0] * EB[1] * EB[2]) * 32 * 4;
-        if (need <= LDS_LIMIT / 2 || (ci == 3 && need <= LDS_LIMIT)) {
-            found = true;
-            lds = need;
-            tg.TD = T3[0]; tg.TH = T3[1]; tg.TW = T3[2];
-            tg.lTH = T3[1] == 8 ? 3 : 2;
-            tg.lTW = T3[2] == 8 ? 3 : 2;
-            tg.EAh = EA[1]; tg.EAw = EA[2]; tg.nslotsA = EA[0] * EA[1] * EA[2];
-            tg.EBh = EB[1]; tg.EBw = EB[2]; tg.nslotsB = EB[0] * EB[1] * EB[2];
-        }
+        const int nA = EA[0] * EA[1] * EA[2], nB = EB[0] * EB[1] * EB[2];
+        int c = -1;
+        if (nA * 8 <= 13 * 256 && nB * 8 <= 4 * 256) c = 0;
+        else if (nA * 8 <= 2 * 256 && nB * 8 <= 16 * 256) c = 1;
+        if (c < 0) continue;
+        cfg = c;
+        tg.TD = T3[0]; tg.TH = T3[1]; tg.TW = T3[2];
+        tg.lTH = T3[1] == 8 ? 3 : 2;
+        tg.lTW = T3[2] == 8 ? 3 : 2;
+        tg.EAh = EA[1]; tg.EAw = EA[2]; tg.nslotsA = nA;
+        tg.EBh = EB[1]; tg.EBw = EB[2]; tg.nslotsB = nB;
     }
-    if (!found) return -1;
+    if (cfg < 0) return -1;
+    {   // 16-bit reciprocal multipliers, verified exhaustively for the slot range they are used on
+        auto magic = [](int d, int nmax) -> int {
+            int m = (1 << 16) / d + 1;
+            for (int n = 0; n < nmax; n++)
+                if (((n * m) >> 16) != n / d) return -1;
+            return m;
+        };
+        const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
+        const int nmaxA = (cfg == 0 ? 13 : 2) * 32, nmaxB = (cfg == 0 ? 4 : 16) * 32;
+        tg.magAhw = magic(EAhw, nmaxA); tg.magAw = magic(tg.EAw, EAhw);
+        tg.magBhw = magic(EBhw, nmaxB); tg.magBw = magic(tg.EBw, EBhw);
+        if (tg.magAhw < 0 || tg.magAw < 0 || tg.magBhw < 0 || tg.magBw < 0) return -1;
+    }
     for (int a = 0; a < 3; a++) {
         tg.minA[a] = mnA[a];
         tg.minB[a] = mnB[a];
@@ -909,11 +950,13 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     tg.ntd = (g.Do + tg.TD - 1) / tg.TD;
     tg.nth = (g.Ho + tg.TH - 1) / tg.TH;
     tg.ntw = (g.Wo + tg.TW - 1) / tg.TW;
-    tg.ntiles = (long)g.N * tg.ntd * tg.nth * tg.ntw;
+    const long ntiles = (long)g.N * tg.ntd * tg.nth * tg.ntw;
+    if (ntiles > (1L << 30)) return -1;
+    tg.ntiles = (int)ntiles;
     const int ncb = (C + 31) / 32;
     tg.nkb = (g.K + 31) / 32;
     long ns = wgrad_max_split(g);
-    if (ns > tg.ntiles) ns = tg.ntiles;
+    if (ns > ntiles) ns = ntiles;
     tg.nsplit = (int)ns;
     const size_t need_ws = (size_t)tg.nsplit * g.ntaps * C * g.K * sizeof(float);
     if (ws_bytes < need_ws) {
@@ -924,11 +967,12 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     float *partial = reinterpret_cast<float *>(ws);
     const int tpw = (g.ntaps + 3) / 4;
     dim3 grid(tg.nsplit, ncb * tg.nkb);
-#define WG_LAUNCH(TPW)                                                                                             \
+#define WG_LAUNCH(TPW, NA, NB, SH)                                                                                   \
     {                                                                                                              \
-        auto kern = k_wgrad_mfma<TPW>;                                                                             \
+        auto kern = k_wgrad_mfma<TPW, NA, NB, SH>;                                                                  \
+        const size_t lds = (size_t)(NA + NB) * 4096;                                                               \
         static bool cfgd = false;                                                                                  \
-        if (!cfgd && lds > 64 * 1024) {                                                                            \
+        if (!cfgd) {                                                                                               \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)LDS_LIMIT) != hipSuccess) {                                               \
                 set_error("conv wgrad (mfma): cannot raise the dynamic LDS limit");                                \
@@ -938,10 +982,26 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         }                                                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tg, a1, a2, b, partial);                              \
     }
-    if (tpw <= 1) WG_LAUNCH(1)
-    else if (tpw == 2) WG_LAUNCH(2)
-    else if (tpw <= 4) WG_LAUNCH(4)
-    else WG_LAUNCH(7)
+    bool sameA = true, sameB = true;
+    for (int t = 1; t < g.ntaps; t++) {
+        sameA = sameA && tg.toffA[t] == tg.toffA[0];
+        sameB = sameB && tg.toffB[t] == tg.toffB[0];
+    }
+#define WG_TPW(NA, NB, SH)                     \
+    {                                          \
+        if (tpw <= 1) WG_LAUNCH(1, NA, NB, SH) \
+        else if (tpw == 2) WG_LAUNCH(2, NA, NB, SH) \
+        else if (tpw <= 4) WG_LAUNCH(4, NA, NB, SH) \
+        else WG_LAUNCH(7, NA, NB, SH)          \
+    }
+    if (cfg == 0) {
+        if (sameB) WG_TPW(13, 4, 1)
+        else WG_TPW(13, 4, 0)
+    } else {
+        if (sameA) WG_TPW(2, 16, 2)
+        else WG_TPW(2, 16, 0)
+    }
+#undef WG_TPW
 #undef WG_LAUNCH
     if (check_launch("conv wgrad (mfma)")) return 1;
     const long per = (long)g.ntaps * C * g.K;
