@@ -48,6 +48,15 @@ def time_kernel(fn, iters, torch):
     return e0.elapsed_time(e1) / iters
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in their own runs, gfx950 half-count correction applied): profiles/r01_pmc_traffic.json."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def dominant_kernel_roofline(torch, dev):
     """Times the dominant kernel of the step in isolation, live, with HIP events: the 3x3x3 conv forward-type
     implicit GEMM on the most expensive layer (decoder stage 5 conv 0: 64 -> 32 channels at 128^3, two input
@@ -75,7 +84,7 @@ def dominant_kernel_roofline(torch, dev):
     alg_bytes = ((C1 + C2) + K) * N * D * H * W * 4.0
     roof = {"kernel": "conv3d_fwd 64->32 @128^3 (fwd-type implicit GEMM)", "bound": "mfma", "achieved": round(conv_tf, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "ms_per_launch": round(ms, 3),
+            "traffic": measured_traffic(), "ms_per_launch": round(ms, 3),
             "hbm_view": {"algorithmic_GB": round(alg_bytes / 1e9, 3),
                          "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
                          "frac_of_hbm_peak": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
@@ -93,23 +102,47 @@ def dominant_kernel_roofline(torch, dev):
     return roof
 
 
+def usable_cores():
+    """Host cores this process may actually use: CPU affinity capped by the cgroup quota (the GPU box exposes all
+    host CPUs to os.cpu_count() but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(torch):
     """The oracle's torch-CPU train step (same ops, same order as the reference's `-device cpu` path,
-    run_training.py:391-395: all host threads, no autocast) on a bounded sample: ONE step at batch 1 of the same
-    4x128^3 workload."""
+    run_training.py:391-395: all usable host threads, no autocast) on a BOUNDED sample of the workload: ONE train step,
+    batch 1, of the same 6-stage 4-modality network on a 64^3 sub-patch (1/8 of the 128^3 patch's voxels; every layer
+    is convolutional, so cost scales with voxels).  `value` is converted to 128^3-patch samples/s (x 1/8)."""
     from oracle import loss_oracle as LO, step_oracle as SO, unet_oracle as UO
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    sub = (64, 64, 64)
     net = UO.build_plainconv_unet(IN_CH, NUM_CLASSES, 6, STRIDES, seed=0)
-    batch = SO.synthetic_batch(1, IN_CH, PATCH, STRIDES, num_classes=NUM_CLASSES, seed=1234)
+    batch = SO.synthetic_batch(1, IN_CH, sub, STRIDES, num_classes=NUM_CLASSES, seed=1234)
     loss_fn = LO.build_loss(len(batch["target"]))
     opt = SO.make_optimizer(net.parameters())
     t0 = time.perf_counter()
     SO.train_step(net, loss_fn, opt, batch)
     dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step (fwd+loss+bwd+clip+SGD), batch 1, 4x128^3, torch {torch.__version__} CPU fp32, "
-                      f"{dt:.1f} s wall (first step, includes oneDNN primitive creation)"}
+    frac = (sub[0] * sub[1] * sub[2]) / float(PATCH[0] * PATCH[1] * PATCH[2])
+    return {"value": round(frac / dt, 5), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 train step (fwd+loss+bwd+clip+SGD), batch 1, 4x64^3 sub-patch of the 4x128^3 workload, torch "
+                      f"{torch.__version__} CPU fp32, {cores} threads: {dt:.1f} s wall (first step, includes oneDNN "
+                      f"primitive creation); value = (64^3/128^3) / wall"}
 
 
 def main():
