@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--patch", type=int, nargs=3, default=list(PATCH), help="debug only; the metric is quoted at 128^3")
+    ap.add_argument("--backend", default="nccl", help="debug only: 'gloo' lets several ranks share one GPU")
     args = ap.parse_args()
 
     import torch
@@ -164,11 +165,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL over xGMI on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)  # nccl == RCCL over xGMI on ROCm
 
     from multimodal_mvd_seg_amd import trainer
     patch = tuple(args.patch)

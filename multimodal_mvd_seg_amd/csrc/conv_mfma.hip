@@ -845,6 +845,125 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ narrow-input wgrad
+// C <= 8 with ntaps*C <= 128 (the 4-modality input layer: 27 taps x 4 channels = 108 rows).  Padding C to a 32-row M
+// tile per tap wastes 7/8 of the MFMAs; here the GEMM M index is the (tap, channel) pair: wave w owns rows
+// 32w..32w+31, one MFMA per voxel pair.  A tile in LDS is [slots][C] (16 B per voxel at C = 4), B tile [128][32 k].
+template <int NAS, int NB>
+__global__ __launch_bounds__(256, 2) void k_wgrad_smallc(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+                                                         const float *__restrict__ b, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                               // NAS*256 float4
+    float *Bs = lds + (size_t)NAS * 1024;          // NB*256 float4
+    int *toffs = reinterpret_cast<int *>(Bs + (size_t)NB * 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int kb = blockIdx.y, split = blockIdx.x;
+    const int C = g.C1, K = g.K;
+    const int PARTS = C / 4;
+#pragma unroll
+    for (int t = 0; t < 27; t++)
+        if (tid == t && t < g.ntaps) toffs[t] = tg.toffA[t];
+    __syncthreads();
+    const int row = wave * 32 + i;
+    const bool rvalid = row < g.ntaps * C;
+    const int rtap = rvalid ? row / C : 0, rc = rvalid ? row % C : 0;
+    const int arow = (toffs[rtap] * C + rc) * 4;  // byte offset added to slot*C*4
+    const int k0 = kb * 32;
+    const int kvalid = (K - k0) < 32 ? (K - k0) : 32;
+    const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
+    const int TV = tg.TD * tg.TH * tg.TW;
+    const int na = tg.nslotsA * PARTS, nb = tg.nslotsB * 8;
+    const int tb0 = tg.toffB[0] * 128 + i * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    float4 ra[NAS], rb[NB];
+    auto load_tile = [&](int tile) {
+        unsigned r_ = (unsigned)tile;
+        const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+        const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+        const int td_ = (int)(r_ % (unsigned)tg.ntd);
+        const int n = (int)(r_ / (unsigned)tg.ntd);
+        const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
+        {
+            const int z0 = od0 * g.sa[0] + tg.minA[0], y0 = oh0 * g.sa[1] + tg.minA[1], x0 = ow0 * g.sa[2] + tg.minA[2];
+#pragma unroll
+            for (int u = 0; u < NAS; u++) {
+                const int idx = u * 256 + tid;
+                const int slot = idx / PARTS, part = idx - slot * PARTS;
+                const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
+                const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
+                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < na && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                    ra[u] = *reinterpret_cast<const float4 *>(
+                        a1 + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * C + part * 4);
+            }
+        }
+        {
+            const int z0 = od0 * g.sb[0] + tg.minB[0], y0 = oh0 * g.sb[1] + tg.minB[1], x0 = ow0 * g.sb[2] + tg.minB[2];
+            const int part = tid & 7;
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int idx = u * 256 + tid;
+                const int slot = idx >> 3;
+                const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
+                const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
+                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (part * 4 < kvalid && idx < nb && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
+                    rb[u] = *reinterpret_cast<const float4 *>(
+                        b + ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 4);
+            }
+        }
+    };
+    const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
+    auto read_ops = [&](int s2, float &av, float &bv) {
+        const int v = (s2 < TV ? s2 : TV - 2) + h;
+        const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
+        const int sa_ = ((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2];
+        const int sb_ = ((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2];
+        av = *reinterpret_cast<const float *>(Ab + sa_ * C * 4 + arow);
+        bv = *reinterpret_cast<const float *>(Bb + sb_ * 128 + tb0);
+    };
+    int tile = split;
+    if (tile < tg.ntiles) load_tile(tile);
+    while (tile < tg.ntiles) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NAS; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 256 + tid) * 4) = ra[u];
+#pragma unroll
+        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 256 + tid) * 4) = rb[u];
+        __syncthreads();
+        const int next = tile + tg.nsplit;
+        if (next < tg.ntiles) load_tile(next);
+        float a0, b0, a1_, b1_;
+        read_ops(0, a0, b0);
+        for (int s2 = 0; s2 < TV; s2 += 4) {
+            read_ops(s2 + 2, a1_, b1_);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_ops(s2 + 4, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tile = next;
+    }
+    // D layout: col = lane&31 -> k; row -> (tap, c) pair of this wave
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int rr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (rr < g.ntaps * C && i < kvalid) {
+            const int t = rr / C, c = rr - t * C;
+            partial[(((size_t)split * g.ntaps + t) * C + c) * K + k0 + i] = acc[r];
+        }
+    }
+}
+
 // dw[torch layout] = sum_split partial[split][t][c][k]   (fp32 partials, fp64 sum, fixed order)
 __global__ void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial, float *__restrict__ dw, int nsplit) {
     const int C = g.C1 + g.C2, K = g.K;
@@ -986,6 +1105,21 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     for (int t = 1; t < g.ntaps; t++) {
         sameA = sameA && tg.toffA[t] == tg.toffA[0];
         sameB = sameB && tg.toffB[t] == tg.toffB[0];
+    }
+    if (cfg == 0 && sameB && g.C2 == 0 && C <= 8 && C % 4 == 0 && g.ntaps * C <= 128 && tg.nslotsA * (C / 4) <= 2 * 256) {
+        // narrow-input layer: rows of the GEMM are (tap, channel) pairs
+        long ns2 = 512 / tg.nkb;
+        if (ns2 < 1) ns2 = 1;
+        if (ns2 > tg.nsplit * 2) ns2 = tg.nsplit * 2;
+        if (ns2 > ntiles) ns2 = ntiles;
+        if ((size_t)ns2 * g.ntaps * C * g.K * sizeof(float) <= ws_bytes) tg.nsplit = (int)ns2;
+        auto kern = k_wgrad_smallc<2, 4>;
+        const size_t lds2 = (size_t)(2 + 4) * 4096 + 32 * 4;
+        hipLaunchKernelGGL(kern, dim3(tg.nsplit, tg.nkb), dim3(256), lds2, s, g, tg, a1, b, partial);
+        if (check_launch("conv wgrad (mfma, narrow input)")) return 1;
+        const long per2 = (long)g.ntaps * C * g.K;
+        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per2, 256)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
+        return check_launch("conv wgrad reduce (mfma)");
     }
 #define WG_TPW(NA, NB, SH)                     \
     {                                          \
