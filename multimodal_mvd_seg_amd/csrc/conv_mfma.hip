@@ -284,18 +284,10 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
     static_assert(TG * 2 * KT * 4 % 256 == 0, "weight group must be a multiple of 256 float4");
     float *Xs = lds;
     float *Wsm = lds + (size_t)XR * 32 * XS;     // halo buffer sized for XR*32 >= nslots slots
-    int *tapoff = reinterpret_cast<int *>(Wsm + 2 * WBUF);
-    int *wts = tapoff + 32;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < 27; t++)
-        if (tid == t && t < g.ntaps) {
-            tapoff[t] = tg.toff[t];
-            wts[t] = g.wt[t];
-        }
     // XCD-contiguous item order (blocks b and b+8 share an XCD): block b takes item (b%8)*ceil(n/8) + b/8
     const int per_xcd = (tg.nitems + 7) >> 3;
     int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
@@ -328,20 +320,27 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
             for (int r = 0; r < 16; r++) acc[m][q][r] = 0.f;
 
     float4 wr[WR];
-    // weight group `gidx` of chunk `cc` -> registers.  idx = u*256 + tid = ((tl*2+hh)*KT + k)*4 + e4: with 256
-    // threads the tap of slot u is a compile-time function of u (block-uniform condition, no lane mask)
+    // weight group `gidx` of chunk `cc` -> registers.  float4 index inside the group: idx = u*256 + tid =
+    // ((tl*2+hh)*KT + k)*4 + e4; with 256 threads the tap of slot u is a compile-time function of u, so the tap id is
+    // wave-uniform (scalar load from the kernel arguments) and the per-thread part of the address is loop invariant.
+    int woff[WR];
+#pragma unroll
+    for (int u = 0; u < WR; u++) {
+        const int idx = u * 256 + tid;
+        const int e4 = idx & 3, k = (idx >> 2) % KT;
+        const int hh = (NT == 1) ? (tid >> 7) : (u & 1);
+        woff[u] = (hh * tg.K + kb * KT + k) * 16 + e4 * 4;
+    }
     auto load_w = [&](int cc, int gidx) {
 #pragma unroll
         for (int u = 0; u < WR; u++) {
-            const int idx = u * 256 + tid;
-            const int e4 = idx & 3, k = (idx >> 2) % KT;
             const int tl = (NT == 1) ? u : (u >> 1);
-            const int hh = (NT == 1) ? (tid >> 7) : (u & 1);
-            const int t = gidx * TG + tl;
+            const int t = gidx * TG + tl;  // uniform
             wr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < g.ntaps && !(tg.dbg & 1))
-                wr[u] = *reinterpret_cast<const float4 *>(
-                    w + ((((size_t)cc * g.T + wts[t]) * 2 + hh) * tg.K + (size_t)kb * KT + k) * 16 + e4 * 4);
+            if (t < g.ntaps && !(tg.dbg & 1)) {
+                const int wt = g.wt[t];
+                wr[u] = *reinterpret_cast<const float4 *>(w + ((size_t)cc * g.T + wt) * 2 * tg.K * 16 + woff[u]);
+            }
         }
     };
     auto store_w = [&](int buf) {
@@ -353,7 +352,6 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
     };
 
     const int cc_begin = split * nch / tg.S, cc_end = (split + 1) * nch / tg.S;
-    __syncthreads();  // tapoff / wts visible
     for (int cc = cc_begin; cc < cc_end; cc++) {
         const int c0 = cc * 32;
         const float *src;
@@ -397,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
                 for (int tl = 0; tl < TG; tl++) {
                     const int t = gi * TG + tl;
                     if (t < g.ntaps) {  // block-uniform
-                        const int to = tapoff[t];
+                        const int to = tg.toff[t];  // uniform index: scalar load
                         float4 af[MT][4], bf[NT][4];
 #pragma unroll
                         for (int m = 0; m < MT; m++) {
@@ -496,7 +494,7 @@ static int launch_fwd32(const FwdGeom &g, Fwd32Tile &tg, const float *a1, const 
                         const float *bias, float *y1, float *y2, void *ws, size_t ws_bytes, hipStream_t s) {
     auto kern = k_fwd32<NT, MT, TG>;
     constexpr int XR = MT == 2 ? 19 : 12;
-    const size_t lds = ((size_t)XR * 32 * 36 + 2 * (size_t)TG * 2 * (32 * NT) * 20) * 4 + 64 * 4;
+    const size_t lds = ((size_t)XR * 32 * 36 + 2 * (size_t)TG * 2 * (32 * NT) * 20) * 4;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
