@@ -132,6 +132,119 @@ __global__ void k_in_apply(const float *__restrict__ x, const float *__restrict_
     }
 }
 
+// row-mapped apply (C % 4 == 0): thread = (4-channel group g, row r); the per-channel parameters live in registers,
+// each thread streams float4 rows v = v0 + r, v0 + r + R, ... of its block's voxel chunk (no per-element index math)
+__global__ void k_in_apply_rows(const float *__restrict__ x, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, const float *__restrict__ mean,
+                                const float *__restrict__ rstd, float *__restrict__ y, int C, int CG, int R, long V,
+                                long chunk, float slope) {
+    const int n = blockIdx.y, t = threadIdx.x;
+    const int g = t % CG, r = t / CG;
+    if (r >= R) return;
+    const long v0 = (long)blockIdx.x * chunk;
+    long v1 = v0 + chunk;
+    if (v1 > V) v1 = V;
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = g * 4 + i;
+        mu[i] = mean[(size_t)n * C + c];
+        rs[i] = rstd[(size_t)n * C + c];
+        ga[i] = gamma[c];
+        be[i] = beta[c];
+    }
+    const size_t base = ((size_t)n * V) * C + (size_t)g * 4;
+    long v = v0 + r;
+    for (; v + 3L * R < v1; v += 4L * R) {  // four independent rows in flight
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const float4 *>(x + base + (size_t)(v + (long)u * R) * C);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float f[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float xh = (f[i] - mu[i]) * rs[i];
+                const float z = xh * ga[i] + be[i];
+                f[i] = z > 0.f ? z : z * slope;
+            }
+            *reinterpret_cast<float4 *>(y + base + (size_t)(v + (long)u * R) * C) = make_float4(f[0], f[1], f[2], f[3]);
+        }
+    }
+    for (; v < v1; v += R) {
+        float4 q = *reinterpret_cast<const float4 *>(x + base + (size_t)v * C);
+        float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float xh = (f[i] - mu[i]) * rs[i];
+            const float z = xh * ga[i] + be[i];
+            f[i] = z > 0.f ? z : z * slope;
+        }
+        *reinterpret_cast<float4 *>(y + base + (size_t)v * C) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+}
+
+__global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__restrict__ dy,
+                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                    const float *__restrict__ mean, const float *__restrict__ rstd,
+                                    const float *__restrict__ sums, float *__restrict__ dx, int C, int CG, int R, long V,
+                                    long chunk, float slope) {
+    const int n = blockIdx.y, t = threadIdx.x;
+    const int g = t % CG, r = t / CG;
+    if (r >= R) return;
+    const long v0 = (long)blockIdx.x * chunk;
+    long v1 = v0 + chunk;
+    if (v1 > V) v1 = V;
+    const float invV = 1.0f / (float)V;
+    float mu[4], rs[4], ga[4], be[4], m1[4], m2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = g * 4 + i;
+        const size_t nc = (size_t)n * C + c;
+        mu[i] = mean[nc];
+        rs[i] = rstd[nc];
+        ga[i] = gamma[c];
+        be[i] = beta[c];
+        m1[i] = sums[nc * 2 + 0] * invV;
+        m2[i] = sums[nc * 2 + 1] * invV;
+    }
+    const size_t base = ((size_t)n * V) * C + (size_t)g * 4;
+    long v = v0 + r;
+    for (; v + 1L * R < v1; v += 2L * R) {  // two rows (four loads) in flight
+        float4 q[2], e[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            q[u] = *reinterpret_cast<const float4 *>(x + base + (size_t)(v + (long)u * R) * C);
+            e[u] = *reinterpret_cast<const float4 *>(dy + base + (size_t)(v + (long)u * R) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            float f[4] = {q[u].x, q[u].y, q[u].z, q[u].w}, d[4] = {e[u].x, e[u].y, e[u].z, e[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float xh = (f[i] - mu[i]) * rs[i];
+                const float z = xh * ga[i] + be[i];
+                const float dz = z > 0.f ? d[i] : d[i] * slope;
+                f[i] = ga[i] * rs[i] * (dz - m1[i] - xh * m2[i]);
+            }
+            *reinterpret_cast<float4 *>(dx + base + (size_t)(v + (long)u * R) * C) = make_float4(f[0], f[1], f[2], f[3]);
+        }
+    }
+    for (; v < v1; v += R) {
+        float4 q = *reinterpret_cast<const float4 *>(x + base + (size_t)v * C);
+        float4 e = *reinterpret_cast<const float4 *>(dy + base + (size_t)v * C);
+        float f[4] = {q.x, q.y, q.z, q.w}, d[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float xh = (f[i] - mu[i]) * rs[i];
+            const float z = xh * ga[i] + be[i];
+            const float dz = z > 0.f ? d[i] : d[i] * slope;
+            f[i] = ga[i] * rs[i] * (dz - m1[i] - xh * m2[i]);
+        }
+        *reinterpret_cast<float4 *>(dx + base + (size_t)v * C) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+}
+
 // ---- bwd pass 1: partial[n][b][c][2] = (sum dz, sum dz*xhat)
 template <int VEC>
 __global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restrict__ dy,
@@ -301,8 +414,16 @@ int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta
     long bx = cdiv(per_n, 256);
     long cap = 4096 / N > 0 ? 4096 / N : 1;
     if (bx > cap) bx = cap;
-    if (v4)
-        hipLaunchKernelGGL(k_in_apply<4>, dim3(bx, N), dim3(256), 0, s, x, gamma, beta, mean, rstd, y, C, V, slope);
+    if (v4) {
+        // apply pass: more, smaller voxel chunks than the statistics pass (pure streaming, no reduction)
+        long nb2 = V / ((long)g.R * 8);
+        if (nb2 < 1) nb2 = 1;
+        long cap2 = 8192 / N > 0 ? 8192 / N : 1;
+        if (nb2 > cap2) nb2 = cap2;
+        const long chunk2 = cdiv(V, nb2);
+        hipLaunchKernelGGL(k_in_apply_rows, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, s, x, gamma, beta, mean,
+                           rstd, y, C, g.CG, g.R, V, chunk2, slope);
+    }
     else
         hipLaunchKernelGGL(k_in_apply<1>, dim3(bx, N), dim3(256), 0, s, x, gamma, beta, mean, rstd, y, C, V, slope);
     return check_launch("instnorm apply");
@@ -336,9 +457,15 @@ int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, 
     long bx = cdiv(per_n, 256);
     long cap = 4096 / N > 0 ? 4096 / N : 1;
     if (bx > cap) bx = cap;
-    if (v4)
-        hipLaunchKernelGGL(k_in_bwd_apply<4>, dim3(bx, N), dim3(256), 0, s, x, dy, gamma, beta, mean, rstd, sums, dx, C,
-                           V, slope);
+    if (v4) {
+        long nb2 = V / ((long)g.R * 8);
+        if (nb2 < 1) nb2 = 1;
+        long cap2 = 8192 / N > 0 ? 8192 / N : 1;
+        if (nb2 > cap2) nb2 = cap2;
+        const long chunk2 = cdiv(V, nb2);
+        hipLaunchKernelGGL(k_in_bwd_apply_rows, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, s, x, dy, gamma, beta,
+                           mean, rstd, sums, dx, C, g.CG, g.R, V, chunk2, slope);
+    }
     else
         hipLaunchKernelGGL(k_in_bwd_apply<1>, dim3(bx, N), dim3(256), 0, s, x, dy, gamma, beta, mean, rstd, sums, dx, C,
                            V, slope);
