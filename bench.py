@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--patch", type=int, nargs=3, default=list(PATCH), help="debug only; the metric is quoted at 128^3")
     ap.add_argument("--backend", default="nccl", help="debug only: 'gloo' lets several ranks share one GPU")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
+                    help="cfg2 = the metric's workload (default); cfg3 = + mutual-distillation dual branch (KL on the "
+                         "vessel logits + feature KL); cfg4 = cfg3 + soft-clDice topology term (both fp32 this round)")
     args = ap.parse_args()
 
     import torch
@@ -175,9 +178,15 @@ def main():
     from multimodal_mvd_seg_amd import trainer
     patch = tuple(args.patch)
     plans = trainer.make_plans(patch, STRIDES, batch_size=PER_GPU_BATCH * world)
-    tr = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, dataset_json(), device=dev)
+    if args.config == "cfg2":
+        tr = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, dataset_json(), device=dev)
+    else:
+        tr = trainer.ContrastiveTrainerMI355(plans, "3d_fullres", 0, dataset_json(), device=dev)
+        tr.use_topo = args.config == "cfg4"
     torch.manual_seed(0)
     tr.initialize()
+    if args.config != "cfg2":
+        tr.dummy_batch = tr.make_dummy_batch()
     assert tr.batch_size == PER_GPU_BATCH
     tr.on_train_epoch_start()
     batch = tr.dummy_batch  # resident in HBM
@@ -207,7 +216,8 @@ def main():
         out = {"metric": METRIC, "value": round(samples / dt, 4), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: PlainConvUNet 3d_fullres 6 stages 31.2M params, "
+               "config": {"workload": ("BASELINE configs[1]" if args.config == "cfg2" else f"BASELINE {args.config} (dual-branch MVD step)") +
+                                      ": PlainConvUNet 3d_fullres 6 stages 31.2M params, "
                                       f"{IN_CH}x{'x'.join(map(str, patch))} patch, {NUM_CLASSES} classes, fp32, "
                                       "DC+CE deep supervision, SGD-Nesterov+clip",
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,

@@ -79,6 +79,24 @@ int mvd_convT3d_wgrad(const float *x, const float *dy, float *dw, float *dbias, 
                       int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * bf16 mixed precision (BASELINE cfg 4/5: the reference's autocast path, nnUNetTrainer.py:906): activations and
+ * packed weights are bf16 (uint16_t storage), accumulation and bias fp32, outputs bf16; master weights and all
+ * weight gradients stay fp32.  C % 32 == 0 and K % 32 == 0 (the 4-modality input layer runs on the fp32 entry points).
+ * mvd_pack_weight_bf16: torch fp32 weight -> wf16 (reduce C, produce K) / wb16 (reduce K, produce C), layout
+ * [chunk32][tap][kstep][lane half][out channel][8]. */
+int mvd_pack_weight_bf16(const float *w, uint16_t *wf, uint16_t *wb, int K, int C, int T, int transposed, void *stream);
+int mvd_conv3d_fwd_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *wf, const float *bias,
+                        uint16_t *y, int N, int D, int H, int W, int K, const int ksize[3], const int stride[3],
+                        void *ws, size_t ws_bytes, void *stream);
+int mvd_conv3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, uint16_t *dx2, int C2, int N,
+                          int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                          void *stream);
+int mvd_convT3d_fwd_bf16(const uint16_t *x, const uint16_t *wf, const float *bias, uint16_t *y, int N, int D, int H, int W,
+                         int C, int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
+int mvd_convT3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx, int N, int D, int H, int W, int C, int K,
+                           const int stride[3], void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine) + LeakyReLU(slope), fused (K3/K4).  Replaces nn.InstanceNorm3d + nn.LeakyReLU of
  * every ConvDropoutNormReLU (get_network_from_plans.py:41-44).  x,y: [N,V,C] NDHWC with V = D*H*W.
  * Biased variance over V, no running stats.  mean/rstd [N][C] are outputs (saved for backward).

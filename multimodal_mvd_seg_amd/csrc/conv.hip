@@ -298,6 +298,17 @@ static int run_wgrad(const WgradGeom &g, const float *a1, const float *a2, const
     return wgrad_scalar(g, a1, a2, b, dw, ws, ws_bytes, s);
 }
 
+static int run_fwd16(const FwdGeom &g, const uint16_t *a1, const uint16_t *a2, const uint16_t *w, const float *bias,
+                     uint16_t *y1, uint16_t *y2, void *ws, size_t ws_bytes, hipStream_t s) {
+    int r = fwd_bf16(g, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+    if (r < 0) {
+        set_error("bf16 conv engine: unsupported shape (needs C %% 32 == 0 and K %% 32 == 0; C=%d+%d K=%d+%d)", g.C1, g.C2,
+                  g.K1, g.K2);
+        return 3;
+    }
+    return r;
+}
+
 static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 }  // namespace mvd
@@ -534,5 +545,138 @@ int mvd_convT3d_wgrad(const float *x, const float *dy, float *dw, float *dbias, 
         if (r) return r;
     }
     return run_wgrad(g, x, nullptr, dy, dw, ws, ws_bytes, s);
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 twins
+int mvd_pack_weight_bf16(const float *w, uint16_t *wf, uint16_t *wb, int K, int C, int T, int transposed, void *stream) {
+    MVD_REQUIRE(w && (wf || wb) && K > 0 && C > 0 && T > 0 && T <= MVD_MAX_TAPS, "pack_weight_bf16: bad arguments");
+    MVD_REQUIRE(!wf || C % 32 == 0, "pack_weight_bf16: wf needs C %% 32 == 0");
+    MVD_REQUIRE(!wb || K % 32 == 0, "pack_weight_bf16: wb needs K %% 32 == 0");
+    return pack_weight16(w, wf, wb, K, C, T, transposed, as_stream(stream));
+}
+
+int mvd_conv3d_fwd_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *wf, const float *bias, uint16_t *y, int N,
+                   int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                   void *stream) {
+    MVD_REQUIRE(x1 && wf && y && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_fwd_bf16: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_fwd_bf16: bad shape");
+    if (check_ks(ksize, stride, "conv3d_fwd_bf16")) return 2;
+    FwdGeom g;
+    conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    return run_fwd16(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+int mvd_conv3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, uint16_t *dx2, int C2, int N, int D, int H, int W,
+                     int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(dy && wb && dx1 && C1 > 0 && C2 >= 0 && (C2 == 0 || dx2), "conv3d_dgrad_bf16: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_dgrad_bf16: bad shape");
+    if (check_ks(ksize, stride, "conv3d_dgrad_bf16")) return 2;
+    const int dims[3] = {D, H, W};
+    int od[3], pad[3];
+    for (int a = 0; a < 3; a++) {
+        od[a] = out_dim(dims[a], ksize[a], stride[a]);
+        pad[a] = (ksize[a] - 1) / 2;
+    }
+    // one launch per output-parity class (1 class per stride-1 axis, 2 per stride-2 axis)
+    for (int pd = 0; pd < stride[0]; pd++)
+        for (int ph = 0; ph < stride[1]; ph++)
+            for (int pw = 0; pw < stride[2]; pw++) {
+                const int p[3] = {pd, ph, pw};
+                FwdGeom g;
+                memset(&g, 0, sizeof(g));
+                g.N = N;
+                g.Di = od[0]; g.Hi = od[1]; g.Wi = od[2];
+                g.Dy = D; g.Hy = H; g.Wy = W;
+                int grid[3];
+                bool empty = false;
+                for (int a = 0; a < 3; a++) {
+                    grid[a] = (dims[a] - p[a] + stride[a] - 1) / stride[a];
+                    if (grid[a] <= 0) empty = true;
+                    g.sa[a] = 1;
+                    g.so[a] = stride[a];
+                    g.oo[a] = p[a];
+                }
+                if (empty) continue;
+                g.Do = grid[0]; g.Ho = grid[1]; g.Wo = grid[2];
+                g.C1 = K; g.C2 = 0; g.K1 = C1; g.K2 = C2;
+                int nt = 0;
+                for (int ta = 0; ta < ksize[0]; ta++)
+                    for (int tb = 0; tb < ksize[1]; tb++)
+                        for (int tc = 0; tc < ksize[2]; tc++) {
+                            const int t3[3] = {ta, tb, tc};
+                            int off[3];
+                            bool ok = true;
+                            for (int a = 0; a < 3; a++) {
+                                int num = p[a] + pad[a] - t3[a];  // dy index q: q*s + t - pad = o*s + p
+                                if (num % stride[a] != 0) { ok = false; break; }
+                                off[a] = num / stride[a];
+                            }
+                            if (!ok) continue;
+                            for (int a = 0; a < 3; a++) g.off[nt][a] = (int8_t)off[a];
+                            g.wt[nt] = (int8_t)((ta * ksize[1] + tb) * ksize[2] + tc);
+                            nt++;
+                        }
+                g.ntaps = nt;
+                g.T = ksize[0] * ksize[1] * ksize[2];
+                if (nt == 0) continue;
+                int r = run_fwd16(g, dy, nullptr, wb, nullptr, dx1, dx2, ws, ws_bytes, as_stream(stream));
+                if (r) return r;
+            }
+    return 0;
+}
+
+int mvd_convT3d_fwd_bf16(const uint16_t *x, const uint16_t *wf, const float *bias, uint16_t *y, int N, int D, int H, int W, int C, int K,
+                    const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && wf && y && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_fwd_bf16: bad arguments");
+    for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_fwd_bf16: stride must be 1 or 2");
+    for (int pd = 0; pd < stride[0]; pd++)
+        for (int ph = 0; ph < stride[1]; ph++)
+            for (int pw = 0; pw < stride[2]; pw++) {
+                FwdGeom g;
+                memset(&g, 0, sizeof(g));
+                g.N = N;
+                g.Di = g.Do = D; g.Hi = g.Ho = H; g.Wi = g.Wo = W;
+                g.Dy = D * stride[0]; g.Hy = H * stride[1]; g.Wy = W * stride[2];
+                g.C1 = C; g.K1 = K;
+                g.ntaps = 1;
+                g.T = stride[0] * stride[1] * stride[2];
+                g.wt[0] = (int8_t)((pd * stride[1] + ph) * stride[2] + pw);
+                const int p[3] = {pd, ph, pw};
+                for (int a = 0; a < 3; a++) {
+                    g.sa[a] = 1;
+                    g.so[a] = stride[a];
+                    g.oo[a] = p[a];
+                }
+                int r = run_fwd16(g, x, nullptr, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream));
+                if (r) return r;
+            }
+    return 0;
+}
+
+int mvd_convT3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx, int N, int D, int H, int W, int C, int K,
+                      const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(dy && wb && dx && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_dgrad_bf16: bad arguments");
+    for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_dgrad_bf16: stride must be 1 or 2");
+    FwdGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N;
+    g.Di = D * stride[0]; g.Hi = H * stride[1]; g.Wi = W * stride[2];
+    g.Do = g.Dy = D; g.Ho = g.Hy = H; g.Wo = g.Wy = W;
+    g.C1 = K; g.K1 = C;
+    int t = 0;
+    for (int pd = 0; pd < stride[0]; pd++)
+        for (int ph = 0; ph < stride[1]; ph++)
+            for (int pw = 0; pw < stride[2]; pw++) {
+                g.off[t][0] = pd; g.off[t][1] = ph; g.off[t][2] = pw;
+                g.wt[t] = t;
+                t++;
+            }
+    g.ntaps = g.T = t;
+    for (int a = 0; a < 3; a++) {
+        g.sa[a] = stride[a];
+        g.so[a] = 1;
+        g.oo[a] = 0;
+    }
+    return run_fwd16(g, dy, nullptr, wb, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream));
 }
 }

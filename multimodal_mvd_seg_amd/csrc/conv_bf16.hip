@@ -1,0 +1,382 @@
+// bf16 mixed-precision forward-type conv engine (BASELINE cfg 4/5: bf16 activations, fp32 master weights and
+// accumulation).  v_mfma_f32_32x32x16_bf16: A[row r][k = 8h+j], B[k = 8h+j][col r] (8 bf16 = one 16-byte fragment per
+// lane and k-step), fp32 accumulate, 16x the fp32 MFMA rate -- at 32..64 output channels the kernel is bound by LDS /
+// L2 bandwidth, not by the matrix pipe.
+//
+// Same gathered-tap GEMM as conv_mfma.hip (FwdGeom), C % 32 == 0, K % 32 == 0, any gather stride:
+//   * activations NDHWC bf16: a 32-channel chunk of a voxel is 64 B; halo tile in LDS [slots][32 ch] padded to 80 B;
+//   * packed weights bf16 [chunk][tap][s][h][k][8] (s = 16-channel k-step, h = lane half): the B fragment of lane
+//     (r, h) is one 16-byte read; tap groups stream through a double-buffered LDS ring, next group prefetched into
+//     registers under the current group's MFMAs;
+//   * output bf16 (fp32 bias added in the epilogue); skinny problems split the reduce chunks and go through fp32
+//     partials (k_split_reduce16).
+#include <stdlib.h>
+
+#include "common.h"
+#include "conv_geom.h"
+
+namespace mvd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline unsigned short f2bf(float f) {
+    __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+    return *reinterpret_cast<unsigned short *>(&h);
+}
+
+__host__ __device__ inline size_t widx16(int T, int K, int t, int c, int k) {
+    const int cc = c >> 5, r = c & 31, s = r >> 4, h = (r >> 3) & 1, e = r & 7;
+    return ((((((size_t)cc * T + t) * 2 + s) * 2 + h) * K + k) << 3) + e;
+}
+
+// torch fp32 [K][C][T] (or transposed-conv [C][K][T]) -> wf16 (reduce C, produce K) / wb16 (reduce K, produce C)
+__global__ void k_pack_weight16(const float *__restrict__ w, unsigned short *__restrict__ wf, unsigned short *__restrict__ wb,
+                                int K, int C, int T, int transposed) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)K * C * T;
+    if (i >= total) return;
+    int k = i % K;
+    int c = (i / K) % C;
+    int t = i / ((long)K * C);
+    float v = transposed ? w[((size_t)c * K + k) * T + t] : w[((size_t)k * C + c) * T + t];
+    unsigned short b = f2bf(v);
+    if (wf) wf[widx16(T, K, t, c, k)] = b;
+    if (wb) wb[widx16(T, C, t, k, c)] = b;
+}
+
+struct Fwd16Tile {
+    int EH, EW, nslots;
+    int magW, magHW;
+    int min_off[3];
+    int ntd, nth, ntw, nkb, S;
+    int nitems;
+    int K;
+    int toff[27];
+};
+
+// XR: uint4 (8 bf16) per thread of the halo tile = ceil(nslots*4/256)
+template <int NT, int MT, int TG, int XR>
+__global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
+                                                  const unsigned short *__restrict__ a2,
+                                                  const unsigned short *__restrict__ w, const float *__restrict__ bias,
+                                                  unsigned short *__restrict__ y1, unsigned short *__restrict__ y2,
+                                                  float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    constexpr int KT = 32 * NT;
+    constexpr int XS = 80;                       // bytes per halo slot (64 + 16 pad)
+    constexpr int WROW = 16;                     // bytes per (tap, s, h, k) weight fragment
+    constexpr int WR = TG * 4 * KT / 256;        // uint4 per thread per weight group (TG*2*2*KT fragments)
+    constexpr int WBUF = TG * 4 * KT * WROW;     // bytes per weight buffer
+    static_assert((TG * 4 * KT) % 256 == 0, "weight group must be a multiple of 256 fragments");
+    unsigned char *Xs = lds8;
+    unsigned char *Wsm = lds8 + (size_t)XR * 64 * XS;  // halo buffer sized for XR*64 >= nslots slots
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= tg.nitems) return;
+    unsigned r_ = (unsigned)item;
+    const int kb = (int)(r_ % (unsigned)tg.nkb); r_ /= (unsigned)tg.nkb;
+    const int split = (int)(r_ % (unsigned)tg.S); r_ /= (unsigned)tg.S;
+    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+    const int td_ = (int)(r_ % (unsigned)tg.ntd);
+    const int n = (int)(r_ / (unsigned)tg.ntd);
+
+    const int C = g.C1 + g.C2;
+    const int nch = C / 32;
+    const int ngroups = (g.ntaps + TG - 1) / TG;
+    const int EHW = tg.EH * tg.EW;
+    const int nx = tg.nslots * 4;
+    const int od0 = td_ * 4, oh0 = th_ * (4 * MT), ow0 = tw_ * 8;
+    const int iz0 = od0 * g.sa[0] + tg.min_off[0], iy0 = oh0 * g.sa[1] + tg.min_off[1], ix0 = ow0 * g.sa[2] + tg.min_off[2];
+
+    int sbase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+        sbase[m] = (((wave * g.sa[0]) * tg.EH + (4 * m + (i >> 3)) * g.sa[1]) * tg.EW + (i & 7) * g.sa[2]) * XS + h * 16;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][q][r] = 0.f;
+
+    // weight group: fragment index f = u*256 + tid = ((tl*2 + s)*2 + hh)*KT + k ; tl is a compile-time function of u
+    uint4 wr[WR];
+    int woff[WR];
+    constexpr int FPT = 4 * KT;  // fragments per tap
+#pragma unroll
+    for (int u = 0; u < WR; u++) {
+        const int f = (u * 256 + tid) % FPT;
+        const int k = f % KT, sh = f / KT;  // sh = s*2 + hh
+        woff[u] = (sh * tg.K + kb * KT + k) * 8;  // element offset inside a (chunk, tap) block of 4*K*8 elements
+    }
+    auto load_w = [&](int cc, int gidx) {
+#pragma unroll
+        for (int u = 0; u < WR; u++) {
+            // tap of slot u: FPT = 256 -> u; FPT = 128 -> 2u + (tid >> 7): uniform per wave either way
+            const int t = __builtin_amdgcn_readfirstlane(gidx * TG + (u * 256 + tid) / FPT);
+            wr[u] = make_uint4(0, 0, 0, 0);
+            if (t < g.ntaps) {
+                const int wt = g.wt[t];
+                wr[u] = *reinterpret_cast<const uint4 *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8 + woff[u]);
+            }
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < WR; u++)
+            *reinterpret_cast<uint4 *>(Wsm + (size_t)buf * WBUF + (size_t)(u * 256 + tid) * WROW) = wr[u];
+    };
+
+    const int cc_begin = split * nch / tg.S, cc_end = (split + 1) * nch / tg.S;
+    for (int cc = cc_begin; cc < cc_end; cc++) {
+        const int c0 = cc * 32;
+        const unsigned short *src;
+        int Cs, cofs;
+        if (c0 < g.C1) {
+            src = a1; Cs = g.C1; cofs = c0;
+        } else {
+            src = a2; Cs = g.C2; cofs = c0 - g.C1;
+        }
+        load_w(cc, 0);
+        __syncthreads();  // B1: every wave is done with the previous chunk's LDS
+        {
+            uint4 v[XR];
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                const int idx = u * 256 + tid;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (idx < nx) {
+                    const int slot = idx >> 2;
+                    const int ez = (slot * tg.magHW) >> 20, rem = slot - ez * EHW;
+                    const int ey = (rem * tg.magW) >> 20, ex = rem - ey * tg.EW;
+                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
+                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        v[u] = *reinterpret_cast<const uint4 *>(
+                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid & 3) * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                const int idx = u * 256 + tid;
+                *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * XS + (idx & 3) * 16) = v[u];
+            }
+        }
+        for (int gi = 0; gi < ngroups; gi++) {
+            store_w(gi & 1);
+            __syncthreads();  // B2
+            if (gi + 1 < ngroups) load_w(cc, gi + 1);
+            const unsigned char *wb_ = Wsm + (size_t)(gi & 1) * WBUF;
+#pragma unroll
+            for (int tl = 0; tl < TG; tl++) {
+                const int t = gi * TG + tl;
+                if (t < g.ntaps) {  // block-uniform
+                    const int to = tg.toff[t] * XS;
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        bf16x8 af[MT], bfr[NT];
+#pragma unroll
+                        for (int m = 0; m < MT; m++) {
+                            uint4 q = *reinterpret_cast<const uint4 *>(Xs + sbase[m] + to + s * 32);
+                            af[m] = *reinterpret_cast<bf16x8 *>(&q);
+                        }
+#pragma unroll
+                        for (int q_ = 0; q_ < NT; q_++) {
+                            uint4 q = *reinterpret_cast<const uint4 *>(
+                                wb_ + ((size_t)((tl * 2 + s) * 2 + h) * KT + q_ * 32 + i) * WROW);
+                            bfr[q_] = *reinterpret_cast<bf16x8 *>(&q);
+                        }
+#pragma unroll
+                        for (int m = 0; m < MT; m++)
+#pragma unroll
+                            for (int q_ = 0; q_ < NT; q_++)
+                                acc[m][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[q_], acc[m][q_], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int od = od0 + wave;
+    if (od >= g.Do) return;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            const int k = kb * KT + q * 32 + i;
+            const float bv = (bias && tg.S == 1) ? bias[k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int oh = oh0 + 4 * m + (row >> 3), ow = ow0 + (row & 7);
+                if (oh < g.Ho && ow < g.Wo) {
+                    if (tg.S > 1) {
+                        const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
+                        part[(((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k] = acc[m][q][r];
+                    } else {
+                        const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                                          (ow * g.so[2] + g.oo[2]);
+                        const unsigned short val = f2bf(acc[m][q][r] + bv);
+                        if (k < g.K1)
+                            y1[ov * g.K1 + k] = val;
+                        else
+                            y2[ov * g.K2 + (k - g.K1)] = val;
+                    }
+                }
+            }
+        }
+}
+
+// y[mapped(n,o)][k] = bf16( bias[k] + sum_s part[s][n][o][k] )
+__global__ void k_split_reduce16(const FwdGeom g, const float *__restrict__ part, const float *__restrict__ bias,
+                                 unsigned short *__restrict__ y1, unsigned short *__restrict__ y2, int S) {
+    const int K = g.K1 + g.K2;
+    const size_t per = (size_t)g.N * g.Do * g.Ho * g.Wo * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
+        float s = bias ? bias[idx % K] : 0.f;
+        for (int j = 0; j < S; j++) s += part[(size_t)j * per + idx];
+        const int k = (int)(idx % K);
+        size_t r = idx / K;
+        const int ow = (int)(r % g.Wo);
+        r /= g.Wo;
+        const int oh = (int)(r % g.Ho);
+        r /= g.Ho;
+        const int od = (int)(r % g.Do);
+        const int n = (int)(r / g.Do);
+        const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                          (ow * g.so[2] + g.oo[2]);
+        if (k < g.K1)
+            y1[ov * g.K1 + k] = f2bf(s);
+        else
+            y2[ov * g.K2 + (k - g.K1)] = f2bf(s);
+    }
+}
+
+static const size_t LDS_LIMIT16 = 160 * 1024;
+
+template <int NT, int MT, int TG, int XR>
+static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a1, const unsigned short *a2,
+                        const unsigned short *w, const float *bias, unsigned short *y1, unsigned short *y2, void *ws,
+                        size_t ws_bytes, hipStream_t s) {
+    auto kern = k_fwd16<NT, MT, TG, XR>;
+    const size_t lds = (size_t)XR * 64 * 80 + 2 * (size_t)TG * 4 * (32 * NT) * 16;
+    if (lds > LDS_LIMIT16) return -1;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS_LIMIT16) != hipSuccess) {
+            set_error("conv fwd16: cannot raise the dynamic LDS limit");
+            return 1;
+        }
+        configured = true;
+    }
+    const int K = g.K1 + g.K2;
+    tg.nkb = K / (32 * NT);
+    const long tiles = (long)tg.ntd * tg.nth * tg.ntw;
+    const size_t out_elems = (size_t)g.N * g.Do * g.Ho * g.Wo * K;
+    const long wgs = tiles * tg.nkb * g.N;
+    const int nch = (g.C1 + g.C2) / 32;
+    int S = 1;
+    if (ws && wgs < 256 && nch >= 4) {
+        long want = (512 + wgs - 1) / wgs;
+        if (want > 16) want = 16;
+        if (want > nch / 2) want = nch / 2;
+        while (want > 1 && (size_t)want * out_elems * sizeof(float) > ws_bytes) want--;
+        if (want > 1) S = (int)want;
+    }
+    tg.S = S;
+    const long nitems = tiles * tg.nkb * tg.S * g.N;
+    if (nitems > (1L << 30)) return -1;
+    tg.nitems = (int)nitems;
+    const long grid = ((nitems + 7) / 8) * 8;
+    float *part = reinterpret_cast<float *>(ws);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, g, tg, a1, a2, w, bias, y1, y2, part);
+    if (check_launch("conv fwd16 (bf16 mfma)")) return 1;
+    if (S > 1) {
+        long blocks = cdiv((long)out_elems, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_split_reduce16, dim3(blocks), dim3(256), 0, s, g, part, bias, y1, y2, S);
+        return check_launch("conv fwd16 split reduce");
+    }
+    return 0;
+}
+
+// returns 0 ok, >0 error, -1 unsupported shape
+int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
+             const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s) {
+    const int C = g.C1 + g.C2, K = g.K1 + g.K2;
+    if (g.ntaps < 1 || g.ntaps > 27) return -1;
+    if (C % 32 != 0 || g.C1 % 32 != 0 || g.C2 % 32 != 0) return -1;
+    if (K % 32 != 0 || g.K1 % 32 != 0 || g.K2 % 32 != 0) return -1;
+    if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)w) & 15) return -1;
+    int mn[3] = {127, 127, 127}, mx[3] = {-127, -127, -127};
+    for (int t = 0; t < g.ntaps; t++)
+        for (int a = 0; a < 3; a++) {
+            if (g.off[t][a] < mn[a]) mn[a] = g.off[t][a];
+            if (g.off[t][a] > mx[a]) mx[a] = g.off[t][a];
+        }
+    const int NT = (K % 64 == 0) ? 2 : 1;
+    auto magic = [](int d, int nmax) -> int {
+        int m = (1 << 20) / d + 1;  // 20-bit reciprocal: n < 2048 keeps n*m inside int32
+        if (nmax > 2048) return -1;
+        for (int n = 0; n < nmax; n++)
+            if (((n * m) >> 20) != n / d) return -1;
+        return m;
+    };
+    // tile candidates: 4x8x8 (MT = 2) when its halo fits 640 slots, else 4x4x8
+    for (int MT = 2; MT >= 1; MT--) {
+        Fwd16Tile tg;
+        memset(&tg, 0, sizeof(tg));
+        const int T3[3] = {4, 4 * MT, 8};
+        int E[3];
+        for (int a = 0; a < 3; a++) {
+            E[a] = (T3[a] - 1) * g.sa[a] + (mx[a] - mn[a]) + 1;
+            tg.min_off[a] = mn[a];
+        }
+        tg.EH = E[1]; tg.EW = E[2];
+        tg.nslots = E[0] * E[1] * E[2];
+        const int xr_need = (tg.nslots * 4 + 255) / 256;
+        int XR;
+        if (MT == 2 && xr_need <= 10) XR = 10;
+        else if (MT == 1 && xr_need <= 6) XR = 6;
+        else if (MT == 1 && xr_need <= 22) XR = 22;
+        else continue;
+        tg.magHW = magic(tg.EH * tg.EW, XR * 64);
+        tg.magW = magic(tg.EW, tg.EH * tg.EW);
+        if (tg.magHW < 0 || tg.magW < 0) continue;
+        for (int t = 0; t < g.ntaps; t++)
+            tg.toff[t] = ((g.off[t][0] - mn[0]) * tg.EH + (g.off[t][1] - mn[1])) * tg.EW + (g.off[t][2] - mn[2]);
+        tg.ntd = (g.Do + 3) / 4;
+        tg.nth = (g.Ho + 4 * MT - 1) / (4 * MT);
+        tg.ntw = (g.Wo + 7) / 8;
+        tg.K = K;
+        int r = -1;
+        if (MT == 2) {
+            r = NT == 2 ? launch_fwd16<2, 2, 3, 10>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)
+                        : launch_fwd16<1, 2, 4, 10>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+        } else if (XR == 6) {
+            r = NT == 2 ? launch_fwd16<2, 1, 3, 6>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)
+                        : launch_fwd16<1, 1, 4, 6>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+        } else {
+            r = NT == 2 ? launch_fwd16<2, 1, 3, 22>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)
+                        : launch_fwd16<1, 1, 4, 22>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+        }
+        if (r >= 0) return r;
+    }
+    return -1;
+}
+
+int pack_weight16(const float *w, unsigned short *wf, unsigned short *wb, int K, int C, int T, int transposed,
+                  hipStream_t s) {
+    long total = (long)K * C * T;
+    hipLaunchKernelGGL(k_pack_weight16, dim3(cdiv(total, 256)), dim3(256), 0, s, w, wf, wb, K, C, T, transposed);
+    return check_launch("pack_weight16");
+}
+
+}  // namespace mvd

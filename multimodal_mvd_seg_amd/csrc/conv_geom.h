@@ -71,4 +71,10 @@ size_t wgrad_mfma_ws(const WgradGeom &g);
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
                hipStream_t s);
 
+// bf16 forward-type engine (conv_bf16.hip): bf16 activations / packed weights, fp32 accumulate, bf16 output
+int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
+             const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s);
+int pack_weight16(const float *w, unsigned short *wf, unsigned short *wb, int K, int C, int T, int transposed,
+                  hipStream_t s);
+
 }  // namespace mvd

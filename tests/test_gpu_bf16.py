@@ -1,0 +1,107 @@
+"""GPU tests of the bf16 mixed-precision engine (BASELINE cfg 4/5).  Reference: fp64 evaluation on the SAME
+bf16-rounded inputs and weights (products of bf16 numbers are exact in fp32, accumulation is fp32), rounded to bf16 --
+so the only legitimate difference is the accumulation order and the final rounding: 1 bf16 ulp (2^-8 relative)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close_bf16(a, ref, what):
+    a, ref = a.float().cpu().double(), ref.double()
+    tol = 2.0 ** -7 * ref.abs() + 2e-3 * float(ref.abs().max())
+    err = (a - ref).abs()
+    assert bool((err <= tol).all()), f"{what}: max err {float(err.max()):.3e} at |ref| {float(ref.abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("C1,C2,K,sp,stride,N", [
+    (32, 0, 32, (12, 10, 14), 1, 2),
+    (32, 32, 32, (9, 10, 11), 1, 1),
+    (64, 0, 64, (8, 8, 8), 1, 2),
+    (32, 0, 64, (16, 12, 20), 2, 1),
+    (320, 320, 320, (4, 4, 4), 1, 2),
+    (128, 0, 128, (6, 7, 8), (1, 2, 2), 1),
+])
+def test_conv3d_bf16_fwd_dgrad(C1, C2, K, sp, stride, N):
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    st = (stride,) * 3 if isinstance(stride, int) else stride
+    g = torch.Generator().manual_seed(C1 + K)
+    x1 = bf(torch.randn(N, C1, *sp, generator=g))
+    x2 = bf(torch.randn(N, C2, *sp, generator=g)) if C2 else None
+    w = torch.randn(K, C1 + C2, 3, 3, 3, generator=g) / np.sqrt(27 * (C1 + C2))
+    b = torch.randn(K, generator=g) * 0.1
+    wq = bf(w).double()
+    xs = [t.double().requires_grad_() for t in ([x1, x2] if C2 else [x1])]
+    ref = F.conv3d(torch.cat(xs, 1), wq, b.double(), st, 1)
+    gy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(gy.double())
+    cl = torch.channels_last_3d
+    d1 = x1.to(DEV).contiguous(memory_format=cl)
+    d2 = x2.to(DEV).contiguous(memory_format=cl) if C2 else None
+    T = 27
+    wd = w.to(DEV).contiguous()
+    wf = torch.empty(T * (C1 + C2) * K, dtype=torch.bfloat16, device=DEV)
+    wb = torch.empty(T * (C1 + C2) * K, dtype=torch.bfloat16, device=DEV)
+    call("mvd_pack_weight_bf16", _p(wd), _p(wf), _p(wb), K, C1 + C2, T, 0, _stream())
+    od = tuple(ref.shape[2:])
+    y = torch.empty((N, K, *od), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=cl)
+    ws = torch.empty(max(1024, query("mvd_conv_fwd_workspace_bytes", N, sp[0] * sp[1] * sp[2], max(K, C1 + C2))),
+                     dtype=torch.uint8, device=DEV)
+    D, H, W = sp
+    call("mvd_conv3d_fwd_bf16", _p(d1), C1, _p(d2), C2, _p(wf), _p(b.to(DEV)), _p(y), N, D, H, W, K, i3((3, 3, 3)), i3(st),
+         _p(ws), ws.numel(), _stream())
+    close_bf16(y, ref.detach(), "y")
+    gyd = gy.to(DEV).contiguous(memory_format=cl)
+    dx1 = torch.empty_like(d1)
+    dx2 = torch.empty_like(d2) if C2 else None
+    call("mvd_conv3d_dgrad_bf16", _p(gyd), _p(wb), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3((3, 3, 3)), i3(st), _p(ws),
+         ws.numel(), _stream())
+    close_bf16(dx1, xs[0].grad, "dx1")
+    if C2:
+        close_bf16(dx2, xs[1].grad, "dx2")
+
+
+@pytest.mark.parametrize("C,K,sp,N", [(64, 32, (4, 5, 6), 2), (320, 256, (2, 2, 2), 2)])
+def test_convT3d_bf16_fwd_dgrad(C, K, sp, N):
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    g = torch.Generator().manual_seed(C + K)
+    x = bf(torch.randn(N, C, *sp, generator=g))
+    w = torch.randn(C, K, 2, 2, 2, generator=g) / np.sqrt(C)
+    b = torch.randn(K, generator=g) * 0.1
+    xr = x.double().requires_grad_()
+    ref = F.conv_transpose3d(xr, bf(w).double(), b.double(), 2)
+    gy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(gy.double())
+    cl = torch.channels_last_3d
+    xd = x.to(DEV).contiguous(memory_format=cl)
+    wf = torch.empty(8 * C * K, dtype=torch.bfloat16, device=DEV)
+    wb = torch.empty(8 * C * K, dtype=torch.bfloat16, device=DEV)
+    call("mvd_pack_weight_bf16", _p(w.to(DEV).contiguous()), _p(wf), _p(wb), K, C, 8, 1, _stream())
+    D, H, W = sp
+    y = torch.empty((N, K, 2 * D, 2 * H, 2 * W), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=cl)
+    ws = torch.empty(max(1024, query("mvd_conv_fwd_workspace_bytes", N, D * H * W, max(C, K))), dtype=torch.uint8,
+                     device=DEV)
+    call("mvd_convT3d_fwd_bf16", _p(xd), _p(wf), _p(b.to(DEV)), _p(y), N, D, H, W, C, K, i3((2, 2, 2)), _p(ws), ws.numel(),
+         _stream())
+    close_bf16(y, ref.detach(), "y")
+    dx = torch.empty_like(xd)
+    call("mvd_convT3d_dgrad_bf16", _p(gy.to(DEV).contiguous(memory_format=cl)), _p(wb), _p(dx), N, D, H, W, C, K,
+         i3((2, 2, 2)), _p(ws), ws.numel(), _stream())
+    close_bf16(dx, xr.grad, "dx")
