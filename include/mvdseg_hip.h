@@ -95,6 +95,13 @@ int mvd_convT3d_fwd_bf16(const uint16_t *x, const uint16_t *wf, const float *bia
                          int C, int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
 int mvd_convT3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx, int N, int D, int H, int W, int C, int K,
                            const int stride[3], void *ws, size_t ws_bytes, void *stream);
+/* weight gradients from bf16 activations / bf16 dy: operands widened to fp32 in registers, fp32 MFMA, fp32 partials,
+ * fp64 fixed-order reduce -> fp32 dw (torch layout) and fp32 dbias.  Workspace sizes: the fp32 queries above. */
+int mvd_conv3d_wgrad_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *dy, float *dw,
+                          float *dbias, int N, int D, int H, int W, int K, const int ksize[3], const int stride[3],
+                          void *ws, size_t ws_bytes, void *stream);
+int mvd_convT3d_wgrad_bf16(const uint16_t *x, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W,
+                           int C, int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine) + LeakyReLU(slope), fused (K3/K4).  Replaces nn.InstanceNorm3d + nn.LeakyReLU of

@@ -32,6 +32,10 @@ SIGNATURES = {
     "mvd_convT3d_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
     "mvd_convT3d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mvd_convT3d_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
+    "mvd_conv3d_wgrad_bf16": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
+                                      c_size_t, _P]),
+    "mvd_convT3d_wgrad_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t,
+                                       _P]),
     "mvd_pack_weight_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_conv3d_fwd_bf16": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                     c_size_t, _P]),

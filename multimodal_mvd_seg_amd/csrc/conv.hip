@@ -171,6 +171,7 @@ __global__ void k_colsum(const float *__restrict__ x, double *__restrict__ parti
 }
 
 // K % 4 == 0, K <= 1024: float4 loads, several rows in flight per thread (HBM-bound streaming pass)
+template <bool BF>
 __global__ void k_colsum4(const float *__restrict__ x, double *__restrict__ partial, long rows, int K, long chunk) {
     extern __shared__ double sm4[];  // [R][K]
     const int t = threadIdx.x;
@@ -182,20 +183,27 @@ __global__ void k_colsum4(const float *__restrict__ x, double *__restrict__ part
     if (r1 > rows) r1 = rows;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (r < R) {
-        const float *xp = x + (size_t)g * 4;
+        auto ld = [&](long row) -> float4 {
+            if (BF) {
+                const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(x) + (size_t)row * K + g * 4);
+                return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                                   __uint_as_float(q.y & 0xffff0000u));
+            }
+            return *reinterpret_cast<const float4 *>(x + (size_t)row * K + g * 4);
+        };
         long i = r0 + r;
         for (; i + 3L * R < r1; i += 4L * R) {
-            float4 q0 = *reinterpret_cast<const float4 *>(xp + (size_t)i * K);
-            float4 q1 = *reinterpret_cast<const float4 *>(xp + (size_t)(i + R) * K);
-            float4 q2 = *reinterpret_cast<const float4 *>(xp + (size_t)(i + 2L * R) * K);
-            float4 q3 = *reinterpret_cast<const float4 *>(xp + (size_t)(i + 3L * R) * K);
+            float4 q0 = ld(i);
+            float4 q1 = ld(i + R);
+            float4 q2 = ld(i + 2L * R);
+            float4 q3 = ld(i + 3L * R);
             a0 += (double)((q0.x + q1.x) + (q2.x + q3.x));
             a1 += (double)((q0.y + q1.y) + (q2.y + q3.y));
             a2 += (double)((q0.z + q1.z) + (q2.z + q3.z));
             a3 += (double)((q0.w + q1.w) + (q2.w + q3.w));
         }
         for (; i < r1; i += R) {
-            float4 q = *reinterpret_cast<const float4 *>(xp + (size_t)i * K);
+            float4 q = ld(i);
             a0 += (double)q.x; a1 += (double)q.y; a2 += (double)q.z; a3 += (double)q.w;
         }
         double *o = sm4 + (size_t)r * K + g * 4;
@@ -220,7 +228,7 @@ static size_t colsum_ws(long rows, int K) {
     long chunk;
     return (size_t)colsum_blocks(rows, &chunk) * K * sizeof(double) + 256;
 }
-static int colsum(const float *x, float *out, long rows, int K, void *ws, hipStream_t s) {
+static int colsum(const float *x, float *out, long rows, int K, void *ws, hipStream_t s, bool bf = false) {
     long chunk;
     int nb = colsum_blocks(rows, &chunk);
     double *partial = reinterpret_cast<double *>(ws);
@@ -228,8 +236,15 @@ static int colsum(const float *x, float *out, long rows, int K, void *ws, hipStr
         const int KG = K / 4;
         const int R = 256 / KG > 0 ? 256 / KG : 1;
         const int threads = (R * KG + 63) / 64 * 64;
-        hipLaunchKernelGGL(k_colsum4, dim3(nb), dim3(threads), (size_t)R * K * sizeof(double), s, x, partial, rows, K,
-                           chunk);
+        if (bf)
+            hipLaunchKernelGGL(k_colsum4<true>, dim3(nb), dim3(threads), (size_t)R * K * sizeof(double), s, x, partial, rows,
+                               K, chunk);
+        else
+            hipLaunchKernelGGL(k_colsum4<false>, dim3(nb), dim3(threads), (size_t)R * K * sizeof(double), s, x, partial, rows,
+                               K, chunk);
+    } else if (bf) {
+        set_error("bias grad (bf16): K %% 4 != 0 is not supported");
+        return 2;
     } else {
         hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, s, x, partial, rows, K, chunk);
     }
@@ -304,6 +319,17 @@ static int run_fwd16(const FwdGeom &g, const uint16_t *a1, const uint16_t *a2, c
     if (r < 0) {
         set_error("bf16 conv engine: unsupported shape (needs C %% 32 == 0 and K %% 32 == 0; C=%d+%d K=%d+%d)", g.C1, g.C2,
                   g.K1, g.K2);
+        return 3;
+    }
+    return r;
+}
+
+static int run_wgrad16(const WgradGeom &g, const uint16_t *a1, const uint16_t *a2, const uint16_t *b, float *dw, void *ws,
+                       size_t ws_bytes, hipStream_t s) {
+    int r = wgrad_mfma(g, reinterpret_cast<const float *>(a1), reinterpret_cast<const float *>(a2),
+                       reinterpret_cast<const float *>(b), dw, ws, ws_bytes, s, true);
+    if (r < 0) {
+        set_error("bf16 wgrad: unsupported shape (needs C %% 32 == 0 and K %% 32 == 0; C=%d+%d K=%d)", g.C1, g.C2, g.K);
         return 3;
     }
     return r;
@@ -678,5 +704,38 @@ int mvd_convT3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx,
         g.oo[a] = 0;
     }
     return run_fwd16(g, dy, nullptr, wb, nullptr, dx, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+int mvd_conv3d_wgrad_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *dy, float *dw, float *dbias, int N,
+                     int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                     void *stream) {
+    MVD_REQUIRE(x1 && dy && dw && ws && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_wgrad_bf16: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_wgrad_bf16: bad shape");
+    if (check_ks(ksize, stride, "conv3d_wgrad_bf16")) return 2;
+    WgradGeom g;
+    conv_wgrad_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    MVD_REQUIRE(ws_bytes >= mvd_conv3d_wgrad_workspace_bytes(C1 + C2, K, g.T, N, g.Do, g.Ho, g.Wo),
+                "conv3d_wgrad_bf16: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (dbias) {
+        int r = colsum(reinterpret_cast<const float *>(dy), dbias, (long)N * g.Do * g.Ho * g.Wo, K, ws, s, true);
+        if (r) return r;
+    }
+    return run_wgrad16(g, x1, x2, dy, dw, ws, ws_bytes, s);
+}
+
+int mvd_convT3d_wgrad_bf16(const uint16_t *x, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W, int C, int K,
+                      const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && dy && dw && ws && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_wgrad_bf16: bad arguments");
+    for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_wgrad_bf16: stride must be 1 or 2");
+    WgradGeom g;
+    convT_wgrad_geom(g, N, D, H, W, C, K, stride);
+    MVD_REQUIRE(ws_bytes >= mvd_convT3d_wgrad_workspace_bytes(C, K, g.T, N, D, H, W), "convT3d_wgrad_bf16: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (dbias) {
+        int r = colsum(reinterpret_cast<const float *>(dy), dbias, (long)N * g.Db * g.Hb * g.Wb, K, ws, s, true);
+        if (r) return r;
+    }
+    return run_wgrad16(g, x, nullptr, dy, dw, ws, ws_bytes, s);
 }
 }

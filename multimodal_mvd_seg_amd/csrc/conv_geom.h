@@ -69,7 +69,7 @@ int wgrad_scalar(const WgradGeom &g, const float *a1, const float *a2, const flo
                  size_t ws_bytes, hipStream_t s);
 size_t wgrad_mfma_ws(const WgradGeom &g);
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
-               hipStream_t s);
+               hipStream_t s, bool bf16_in = false);
 
 // bf16 forward-type engine (conv_bf16.hip): bf16 activations / packed weights, fp32 accumulate, bf16 output
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,

@@ -671,7 +671,8 @@ struct WgTile {
 // NA / NB: float4 per thread of the A halo / B tile (LDS regions are NA*4 KiB and NB*4 KiB).  The NEXT tile's A and B
 // are prefetched into registers while the current tile's MFMAs run.
 // SH: 1 = every tap reads the same B slot (3x3x3 conv: B = dy), 2 = the same A slot (transposed conv), 0 = neither
-template <int TPW, int NA, int NB, int SH>
+// BF: A and B are bf16 in HBM (mixed precision); they are widened to fp32 while staging, the MFMAs stay fp32
+template <int TPW, int NA, int NB, int SH, bool BF>
 __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
                                                        const float *__restrict__ a2, const float *__restrict__ b,
                                                        float *__restrict__ partial) {
@@ -738,9 +739,16 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
                 const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
                 const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
                 ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (aok && idx < na && !(tg.dbg & 1) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
-                    ra[u] = *reinterpret_cast<const float4 *>(
-                        asrc + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 4);
+                if (aok && idx < na && !(tg.dbg & 1) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi) {
+                    const size_t e = ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 4;
+                    if (BF) {
+                        const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(asrc) + e);
+                        ra[u] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
+                                            __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+                    } else {
+                        ra[u] = *reinterpret_cast<const float4 *>(asrc + e);
+                    }
+                }
             }
         }
         {
@@ -753,9 +761,16 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
                 const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
                 const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
                 rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (bok && idx < nb && !(tg.dbg & 1) && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
-                    rb[u] = *reinterpret_cast<const float4 *>(
-                        b + ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 4);
+                if (bok && idx < nb && !(tg.dbg & 1) && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb) {
+                    const size_t e = ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 4;
+                    if (BF) {
+                        const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(b) + e);
+                        rb[u] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
+                                            __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
+                    } else {
+                        rb[u] = *reinterpret_cast<const float4 *>(b + e);
+                    }
+                }
             }
         }
     };
@@ -1004,9 +1019,10 @@ size_t wgrad_mfma_ws(const WgradGeom &g) {
 }
 
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
-               hipStream_t s) {
+               hipStream_t s, bool bf16_in) {
     if (!wgrad_mfma_ok(g)) return -1;
     if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)b) & 15) return -1;
+    if (bf16_in && (g.C1 % 32 != 0 || g.C2 % 32 != 0 || g.K % 32 != 0)) return -1;
     const int C = g.C1 + g.C2;
     WgTile tg;
     memset(&tg, 0, sizeof(tg));
@@ -1086,16 +1102,16 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     dim3 grid(tg.nsplit, ncb * tg.nkb);
 #define WG_LAUNCH(TPW, NA, NB, SH)                                                                                   \
     {                                                                                                              \
-        auto kern = k_wgrad_mfma<TPW, NA, NB, SH>;                                                                  \
+        auto kern = bf16_in ? k_wgrad_mfma<TPW, NA, NB, SH, true> : k_wgrad_mfma<TPW, NA, NB, SH, false>;                                                                  \
         const size_t lds = (size_t)(NA + NB) * 4096;                                                               \
-        static bool cfgd = false;                                                                                  \
-        if (!cfgd) {                                                                                               \
+        static bool cfgd[2] = {false, false};                                                                      \
+        if (!cfgd[bf16_in ? 1 : 0]) {                                                                              \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)LDS_LIMIT) != hipSuccess) {                                               \
                 set_error("conv wgrad (mfma): cannot raise the dynamic LDS limit");                                \
                 return 1;                                                                                          \
             }                                                                                                      \
-            cfgd = true;                                                                                           \
+            cfgd[bf16_in ? 1 : 0] = true;                                                                          \
         }                                                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tg, a1, a2, b, partial);                              \
     }
@@ -1104,7 +1120,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         sameA = sameA && tg.toffA[t] == tg.toffA[0];
         sameB = sameB && tg.toffB[t] == tg.toffB[0];
     }
-    if (cfg == 0 && sameB && g.C2 == 0 && C <= 8 && C % 4 == 0 && g.ntaps * C <= 128 && tg.nslotsA * (C / 4) <= 2 * 256) {
+    if (!bf16_in && cfg == 0 && sameB && g.C2 == 0 && C <= 8 && C % 4 == 0 && g.ntaps * C <= 128 && tg.nslotsA * (C / 4) <= 2 * 256) {
         // narrow-input layer: rows of the GEMM are (tap, channel) pairs
         long ns2 = 512 / tg.nkb;
         if (ns2 < 1) ns2 = 1;

@@ -102,6 +102,72 @@ def test_convT3d_bf16_fwd_dgrad(C, K, sp, N):
          _stream())
     close_bf16(y, ref.detach(), "y")
     dx = torch.empty_like(xd)
-    call("mvd_convT3d_dgrad_bf16", _p(gy.to(DEV).contiguous(memory_format=cl)), _p(wb), _p(dx), N, D, H, W, C, K,
-         i3((2, 2, 2)), _p(ws), ws.numel(), _stream())
+    gyd = gy.to(DEV).contiguous(memory_format=cl)  # keep alive across the call
+    call("mvd_convT3d_dgrad_bf16", _p(gyd), _p(wb), _p(dx), N, D, H, W, C, K, i3((2, 2, 2)), _p(ws), ws.numel(), _stream())
     close_bf16(dx, xr.grad, "dx")
+
+
+def close_f32(a, ref, what, rel=2e-5):
+    a, ref = a.float().cpu().double(), ref.double()
+    err = float((a - ref).abs().max())
+    assert err <= rel * float(ref.abs().max()) + 1e-7, f"{what}: max err {err:.3e} at |ref| {float(ref.abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("C1,C2,K,sp,stride,N", [
+    (32, 0, 32, (12, 10, 14), 1, 2),
+    (32, 32, 32, (9, 10, 11), 1, 1),
+    (32, 0, 64, (16, 12, 20), 2, 1),
+    (320, 320, 320, (4, 4, 4), 1, 2),
+    (128, 0, 128, (6, 7, 8), (1, 2, 2), 1),
+])
+def test_conv3d_bf16_wgrad(C1, C2, K, sp, stride, N):
+    """dw/dbias from bf16 x and bf16 dy are fp32-accumulated sums of exact products: compare with fp64 on the same
+    rounded operands at fp32 tolerance."""
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    st = (stride,) * 3 if isinstance(stride, int) else stride
+    g = torch.Generator().manual_seed(7 * C1 + K)
+    x1 = bf(torch.randn(N, C1, *sp, generator=g))
+    x2 = bf(torch.randn(N, C2, *sp, generator=g)) if C2 else None
+    C = C1 + C2
+    w = torch.zeros(K, C, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(K, dtype=torch.float64, requires_grad=True)
+    xin = torch.cat([x1.double(), x2.double()], 1) if C2 else x1.double()
+    ref = F.conv3d(xin, w, b, st, 1)
+    gy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(gy.double())
+    cl = torch.channels_last_3d
+    d1 = x1.to(DEV).contiguous(memory_format=cl)
+    d2 = x2.to(DEV).contiguous(memory_format=cl) if C2 else None
+    gyd = gy.to(DEV).contiguous(memory_format=cl)
+    od = tuple(ref.shape[2:])
+    ws = torch.empty(max(1024, query("mvd_conv3d_wgrad_workspace_bytes", C, K, 27, N, *od)), dtype=torch.uint8, device=DEV)
+    dw = torch.empty(K, C, 3, 3, 3, device=DEV)
+    db = torch.empty(K, device=DEV)
+    D, H, W = sp
+    call("mvd_conv3d_wgrad_bf16", _p(d1), C1, _p(d2), C2, _p(gyd), _p(dw), _p(db), N, D, H, W, K, i3((3, 3, 3)), i3(st),
+         _p(ws), ws.numel(), _stream())
+    close_f32(dw, w.grad, "dw")
+    close_f32(db, b.grad, "dbias")
+
+
+@pytest.mark.parametrize("C,K,sp,N", [(64, 32, (4, 5, 6), 2), (320, 256, (2, 2, 2), 2)])
+def test_convT3d_bf16_wgrad(C, K, sp, N):
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    g = torch.Generator().manual_seed(3 * C + K)
+    x = bf(torch.randn(N, C, *sp, generator=g))
+    w = torch.zeros(C, K, 2, 2, 2, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(K, dtype=torch.float64, requires_grad=True)
+    ref = F.conv_transpose3d(x.double(), w, b, 2)
+    gy = bf(torch.randn(ref.shape, generator=g))
+    ref.backward(gy.double())
+    cl = torch.channels_last_3d
+    D, H, W = sp
+    ws = torch.empty(max(1024, query("mvd_convT3d_wgrad_workspace_bytes", C, K, 8, N, D, H, W)), dtype=torch.uint8,
+                     device=DEV)
+    dw = torch.empty(C, K, 2, 2, 2, device=DEV)
+    db = torch.empty(K, device=DEV)
+    xd, gyd = x.to(DEV).contiguous(memory_format=cl), gy.to(DEV).contiguous(memory_format=cl)  # keep alive
+    call("mvd_convT3d_wgrad_bf16", _p(xd), _p(gyd), _p(dw), _p(db), N, D, H, W, C, K, i3((2, 2, 2)), _p(ws), ws.numel(),
+         _stream())
+    close_f32(dw, w.grad, "dw")
+    close_f32(db, b.grad, "dbias")
