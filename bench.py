@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
                     help="cfg2 = the metric's workload (default); cfg3 = + mutual-distillation dual branch (KL on the "
                          "vessel logits + feature KL); cfg4 = cfg3 + soft-clDice topology term (both fp32 this round)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the metric's configuration (default); bf16 = mixed precision of BASELINE cfg 4/5 (bf16 "
+                         "activations on the bf16 MFMA engine, fp32 master weights/statistics/losses/optimizer)")
     args = ap.parse_args()
 
     import torch
@@ -184,6 +187,7 @@ def main():
         tr = trainer.ContrastiveTrainerMI355(plans, "3d_fullres", 0, dataset_json(), device=dev)
         tr.use_topo = args.config == "cfg4"
     torch.manual_seed(0)
+    tr.precision = args.precision
     tr.initialize()
     if args.config != "cfg2":
         tr.dummy_batch = tr.make_dummy_batch()
@@ -215,10 +219,12 @@ def main():
         samples = PER_GPU_BATCH * world * args.steps
         out = {"metric": METRIC, "value": round(samples / dt, 4), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
+               "data": "synthetic",
                "config": {"workload": ("BASELINE configs[1]" if args.config == "cfg2" else f"BASELINE {args.config} (dual-branch MVD step)") +
                                       ": PlainConvUNet 3d_fullres 6 stages 31.2M params, "
-                                      f"{IN_CH}x{'x'.join(map(str, patch))} patch, {NUM_CLASSES} classes, fp32, "
+                                      f"{IN_CH}x{'x'.join(map(str, patch))} patch, {NUM_CLASSES} classes, "
+                                      f"{'fp32' if args.precision == 'fp32' else 'bf16 mixed precision'}, "
                                       "DC+CE deep supervision, SGD-Nesterov+clip",
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,
                           "parallelism": f"dp{world}"},

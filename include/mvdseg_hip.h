@@ -102,6 +102,23 @@ int mvd_conv3d_wgrad_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2
                           void *ws, size_t ws_bytes, void *stream);
 int mvd_convT3d_wgrad_bf16(const uint16_t *x, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W,
                            int C, int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
+/* InstanceNorm+LeakyReLU with bf16 output (statistics and arithmetic fp32/fp64 as in the fp32 entry points).
+ * x is fp32 (x_is_bf16 == 0: the first, fp32, conv of the network) or bf16; y and dy are bf16; dx has x's type.
+ * Workspace: mvd_instnorm_workspace_bytes.  C % 4 == 0. */
+int mvd_instnorm_lrelu_fwd_bf16(const void *x, int x_is_bf16, const float *gamma, const float *beta, uint16_t *y,
+                                float *mean, float *rstd, int N, long V, int C, float eps, float slope, void *ws,
+                                size_t ws_bytes, void *stream);
+int mvd_instnorm_lrelu_bwd_bf16(const void *x, int x_is_bf16, const uint16_t *dy, const float *gamma, const float *beta,
+                                const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta, int N,
+                                long V, int C, float slope, void *ws, size_t ws_bytes, void *stream);
+/* seg head on bf16 activations: fp32 weights, fp32 planar logits (the loss kernels stay fp32), bf16 dx, fp32 dw/dbias */
+int mvd_seghead_fwd_bf16(const uint16_t *x, const float *w, const float *bias, float *logits, int N, long V, int C,
+                         int K, void *stream);
+int mvd_seghead_bwd_bf16(const uint16_t *x, const float *w, const float *dlogits, uint16_t *dx, float *dw, float *dbias,
+                         int N, long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream);
+/* flat conversions (round-to-nearest-even) for tensors that cross the precision boundary (distillation features) */
+int mvd_cast_f32_to_bf16(const float *src, uint16_t *dst, long n, void *stream);
+int mvd_cast_bf16_to_f32(const uint16_t *src, float *dst, long n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * InstanceNorm3d(eps, affine) + LeakyReLU(slope), fused (K3/K4).  Replaces nn.InstanceNorm3d + nn.LeakyReLU of

@@ -36,6 +36,14 @@ SIGNATURES = {
                                       c_size_t, _P]),
     "mvd_convT3d_wgrad_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t,
                                        _P]),
+    "mvd_instnorm_lrelu_fwd_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, c_float, _P,
+                                            c_size_t, _P]),
+    "mvd_instnorm_lrelu_bwd_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, _P,
+                                            c_size_t, _P]),
+    "mvd_seghead_fwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_long, c_int, c_int, _P]),
+    "mvd_seghead_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "mvd_cast_f32_to_bf16": (c_int, [_P, _P, c_long, _P]),
+    "mvd_cast_bf16_to_f32": (c_int, [_P, _P, c_long, _P]),
     "mvd_pack_weight_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_conv3d_fwd_bf16": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                     c_size_t, _P]),

@@ -38,6 +38,44 @@ inline hipStream_t as_stream(void *s) {
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// bf16 storage helpers (uint16_t bit patterns).  f2bf: v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserved.
+__device__ inline unsigned short f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return *reinterpret_cast<unsigned short *>(&h);
+}
+// 4 consecutive channels at element index e of a float (BF = false) or bf16 (BF = true) tensor, as fp32
+template <bool BF>
+__device__ inline float4 ld4(const void *p, size_t e) {
+    if (BF) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p) + e);
+        return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                           __uint_as_float(q.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + e);
+}
+template <bool BF>
+__device__ inline void st4(void *p, size_t e, float a, float b, float c, float d) {
+    if (BF) {
+        uint2 q;
+        q.x = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+        q.y = (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p) + e) = q;
+    } else {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + e) = make_float4(a, b, c, d);
+    }
+}
+
+template <bool BF>
+__device__ inline float ld1(const void *p, size_t e) {
+    if (BF) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(p)[e] << 16);
+    return reinterpret_cast<const float *>(p)[e];
+}
+template <bool BF>
+__device__ inline void st1(void *p, size_t e, float v) {
+    if (BF) reinterpret_cast<unsigned short *>(p)[e] = f2bf(v);
+    else reinterpret_cast<float *>(p)[e] = v;
+}
+
 // 64-lane wavefront reductions (CDNA wave = 64)
 __device__ inline double wave_sum(double v) {
 #pragma unroll

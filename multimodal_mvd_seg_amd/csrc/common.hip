@@ -76,6 +76,18 @@ __global__ void k_axpy(float *__restrict__ y, const float *__restrict__ x, float
     for (; i < n; i += stride) y[i] = y[i] + a * x[i];
 }
 
+// flat fp32 <-> bf16 conversion, 4 elements per thread (n % 4 tail handled scalar)
+template <bool TO_BF>
+__global__ void k_cast(const void *__restrict__ src, void *__restrict__ dst, long n) {
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 q = ld4<!TO_BF>(src, (size_t)i * 4);
+        st4<TO_BF>(dst, (size_t)i * 4, q.x, q.y, q.z, q.w);
+    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) st1<TO_BF>(dst, (size_t)i, ld1<!TO_BF>(src, (size_t)i));
+}
+
 // torch [K][C][T] (or transposed-conv [C][K][T]) -> wf / wb in the packed layout of conv_geom.h (widx)
 __global__ void k_pack_weight(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wb, int K,
                               int C, int T, int transposed) {
@@ -127,5 +139,19 @@ int mvd_axpy(float *y, const float *x, float a, long n, void *stream) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_axpy, dim3(blocks), dim3(256), 0, as_stream(stream), y, x, a, n);
     return check_launch("axpy");
+}
+int mvd_cast_f32_to_bf16(const float *src, uint16_t *dst, long n, void *stream) {
+    MVD_REQUIRE(src && dst && n > 0, "cast_f32_to_bf16: bad arguments");
+    long blocks = cdiv(cdiv(n, 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_cast<true>, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, n);
+    return check_launch("cast_f32_to_bf16");
+}
+int mvd_cast_bf16_to_f32(const uint16_t *src, float *dst, long n, void *stream) {
+    MVD_REQUIRE(src && dst && n > 0, "cast_bf16_to_f32: bad arguments");
+    long blocks = cdiv(cdiv(n, 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_cast<false>, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, n);
+    return check_launch("cast_bf16_to_f32");
 }
 }

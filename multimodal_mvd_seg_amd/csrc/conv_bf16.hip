@@ -20,11 +20,6 @@ namespace mvd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ inline unsigned short f2bf(float f) {
-    __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
-    return *reinterpret_cast<unsigned short *>(&h);
-}
-
 __host__ __device__ inline size_t widx16(int T, int K, int t, int c, int k) {
     const int cc = c >> 5, r = c & 31, s = r >> 4, h = (r >> 3) & 1, e = r & 7;
     return ((((((size_t)cc * T + t) * 2 + s) * 2 + h) * K + k) << 3) + e;

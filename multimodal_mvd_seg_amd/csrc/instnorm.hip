@@ -35,7 +35,7 @@ static NormGeom norm_geom(int N, long V, int C) {
 }
 
 // ---- pass 1 (fwd): partial[n][b][c][2] = (sum x, sum x^2) in fp64
-template <int VEC>
+template <int VEC, bool XB>
 __global__ void k_in_stats(const float *__restrict__ x, double *__restrict__ partial, int C, int CG, int R, long V,
                            long chunk) {
     extern __shared__ double sm[];  // [R][C][2]
@@ -52,7 +52,7 @@ __global__ void k_in_stats(const float *__restrict__ x, double *__restrict__ par
         const float *xp = x + ((size_t)n * V) * C + (size_t)g * VEC;
         for (long v = v0 + r; v < v1; v += R) {
             if (VEC == 4) {
-                float4 q = *reinterpret_cast<const float4 *>(xp + (size_t)v * C);
+                float4 q = ld4<XB>(x, ((size_t)n * V + v) * C + (size_t)g * 4);
                 float f[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
@@ -134,6 +134,7 @@ __global__ void k_in_apply(const float *__restrict__ x, const float *__restrict_
 
 // row-mapped apply (C % 4 == 0): thread = (4-channel group g, row r); the per-channel parameters live in registers,
 // each thread streams float4 rows v = v0 + r, v0 + r + R, ... of its block's voxel chunk (no per-element index math)
+template <bool XB, bool YB>
 __global__ void k_in_apply_rows(const float *__restrict__ x, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, const float *__restrict__ mean,
                                 const float *__restrict__ rstd, float *__restrict__ y, int C, int CG, int R, long V,
@@ -158,7 +159,7 @@ __global__ void k_in_apply_rows(const float *__restrict__ x, const float *__rest
     for (; v + 3L * R < v1; v += 4L * R) {  // four independent rows in flight
         float4 q[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) q[u] = *reinterpret_cast<const float4 *>(x + base + (size_t)(v + (long)u * R) * C);
+        for (int u = 0; u < 4; u++) q[u] = ld4<XB>(x, base + (size_t)(v + (long)u * R) * C);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             float f[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
@@ -168,11 +169,11 @@ __global__ void k_in_apply_rows(const float *__restrict__ x, const float *__rest
                 const float z = xh * ga[i] + be[i];
                 f[i] = z > 0.f ? z : z * slope;
             }
-            *reinterpret_cast<float4 *>(y + base + (size_t)(v + (long)u * R) * C) = make_float4(f[0], f[1], f[2], f[3]);
+            st4<YB>(y, base + (size_t)(v + (long)u * R) * C, f[0], f[1], f[2], f[3]);
         }
     }
     for (; v < v1; v += R) {
-        float4 q = *reinterpret_cast<const float4 *>(x + base + (size_t)v * C);
+        float4 q = ld4<XB>(x, base + (size_t)v * C);
         float f[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -180,10 +181,11 @@ __global__ void k_in_apply_rows(const float *__restrict__ x, const float *__rest
             const float z = xh * ga[i] + be[i];
             f[i] = z > 0.f ? z : z * slope;
         }
-        *reinterpret_cast<float4 *>(y + base + (size_t)v * C) = make_float4(f[0], f[1], f[2], f[3]);
+        st4<YB>(y, base + (size_t)v * C, f[0], f[1], f[2], f[3]);
     }
 }
 
+template <bool XB, bool YB>
 __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__restrict__ dy,
                                     const float *__restrict__ gamma, const float *__restrict__ beta,
                                     const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -214,8 +216,8 @@ __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__
         float4 q[2], e[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            q[u] = *reinterpret_cast<const float4 *>(x + base + (size_t)(v + (long)u * R) * C);
-            e[u] = *reinterpret_cast<const float4 *>(dy + base + (size_t)(v + (long)u * R) * C);
+            q[u] = ld4<XB>(x, base + (size_t)(v + (long)u * R) * C);
+            e[u] = ld4<YB>(dy, base + (size_t)(v + (long)u * R) * C);
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -227,12 +229,12 @@ __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__
                 const float dz = z > 0.f ? d[i] : d[i] * slope;
                 f[i] = ga[i] * rs[i] * (dz - m1[i] - xh * m2[i]);
             }
-            *reinterpret_cast<float4 *>(dx + base + (size_t)(v + (long)u * R) * C) = make_float4(f[0], f[1], f[2], f[3]);
+            st4<XB>(dx, base + (size_t)(v + (long)u * R) * C, f[0], f[1], f[2], f[3]);
         }
     }
     for (; v < v1; v += R) {
-        float4 q = *reinterpret_cast<const float4 *>(x + base + (size_t)v * C);
-        float4 e = *reinterpret_cast<const float4 *>(dy + base + (size_t)v * C);
+        float4 q = ld4<XB>(x, base + (size_t)v * C);
+        float4 e = ld4<YB>(dy, base + (size_t)v * C);
         float f[4] = {q.x, q.y, q.z, q.w}, d[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -241,12 +243,12 @@ __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__
             const float dz = z > 0.f ? d[i] : d[i] * slope;
             f[i] = ga[i] * rs[i] * (dz - m1[i] - xh * m2[i]);
         }
-        *reinterpret_cast<float4 *>(dx + base + (size_t)v * C) = make_float4(f[0], f[1], f[2], f[3]);
+        st4<XB>(dx, base + (size_t)v * C, f[0], f[1], f[2], f[3]);
     }
 }
 
 // ---- bwd pass 1: partial[n][b][c][2] = (sum dz, sum dz*xhat)
-template <int VEC>
+template <int VEC, bool XB, bool YB>
 __global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restrict__ dy,
                                const float *__restrict__ gamma, const float *__restrict__ beta,
                                const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -275,8 +277,8 @@ __global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restr
         for (long v = v0 + r; v < v1; v += R) {
             float f[VEC], d[VEC];
             if (VEC == 4) {
-                float4 q = *reinterpret_cast<const float4 *>(x + base + (size_t)v * C);
-                float4 e = *reinterpret_cast<const float4 *>(dy + base + (size_t)v * C);
+                float4 q = ld4<XB>(x, base + (size_t)v * C);
+                float4 e = ld4<YB>(dy, base + (size_t)v * C);
                 f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
                 d[0] = e.x; d[1] = e.y; d[2] = e.z; d[3] = e.w;
             } else {
@@ -391,8 +393,8 @@ size_t mvd_instnorm_workspace_bytes(int N, long V, int C) {
     return (size_t)N * g.nblk * C * 2 * sizeof(double) + (size_t)N * C * 2 * sizeof(float) + 256;
 }
 
-int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
-                           int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes, void *stream) {
+static int in_fwd(const float *x, bool xb, const float *gamma, const float *beta, float *y, bool yb, float *mean,
+                  float *rstd, int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "instnorm_fwd: null pointer");
     MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C <= 1024, "instnorm_fwd: bad shape N=%d V=%ld C=%d", N, V, C);
     MVD_REQUIRE(ws_bytes >= mvd_instnorm_workspace_bytes(N, V, C), "instnorm_fwd: workspace too small");
@@ -402,11 +404,14 @@ int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta
     size_t sm = (size_t)g.R * C * 2 * sizeof(double);
     MVD_REQUIRE(sm <= 64 * 1024, "instnorm_fwd: C too large for the LDS reduce");
     const bool v4 = (C % 4 == 0) && (g.CG * 4 == C);
+    MVD_REQUIRE(v4 || !(xb || yb), "instnorm_fwd: bf16 I/O needs C %% 4 == 0");
     dim3 grid(g.nblk, N);
-    if (v4)
-        hipLaunchKernelGGL(k_in_stats<4>, grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+    if (v4 && xb)
+        hipLaunchKernelGGL((k_in_stats<4, true>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+    else if (v4)
+        hipLaunchKernelGGL((k_in_stats<4, false>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
     else
-        hipLaunchKernelGGL(k_in_stats<1>, grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+        hipLaunchKernelGGL((k_in_stats<1, false>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
     if (check_launch("instnorm stats")) return 1;
     hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
     if (check_launch("instnorm finalize")) return 1;
@@ -421,17 +426,19 @@ int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta
         long cap2 = 8192 / N > 0 ? 8192 / N : 1;
         if (nb2 > cap2) nb2 = cap2;
         const long chunk2 = cdiv(V, nb2);
-        hipLaunchKernelGGL(k_in_apply_rows, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, s, x, gamma, beta, mean,
-                           rstd, y, C, g.CG, g.R, V, chunk2, slope);
+        auto kern = xb ? (yb ? k_in_apply_rows<true, true> : k_in_apply_rows<true, false>)
+                       : (yb ? k_in_apply_rows<false, true> : k_in_apply_rows<false, false>);
+        hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, s, x, gamma, beta, mean, rstd, y, C,
+                           g.CG, g.R, V, chunk2, slope);
     }
     else
         hipLaunchKernelGGL(k_in_apply<1>, dim3(bx, N), dim3(256), 0, s, x, gamma, beta, mean, rstd, y, C, V, slope);
     return check_launch("instnorm apply");
 }
 
-int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *mean,
-                           const float *rstd, float *dx, float *dgamma, float *dbeta, int N, long V, int C,
-                           float slope, void *ws, size_t ws_bytes, void *stream) {
+static int in_bwd(const float *x, bool xb, const float *dy, bool yb, const float *gamma, const float *beta,
+                  const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta, int N, long V, int C,
+                  float slope, void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta && ws, "instnorm_bwd: null pointer");
     MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C <= 1024, "instnorm_bwd: bad shape");
     MVD_REQUIRE(ws_bytes >= mvd_instnorm_workspace_bytes(N, V, C), "instnorm_bwd: workspace too small");
@@ -443,12 +450,15 @@ int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, 
     MVD_REQUIRE(sm <= 64 * 1024, "instnorm_bwd: C too large for the LDS reduce");
     const bool v4 = (C % 4 == 0) && (g.CG * 4 == C);
     dim3 grid(g.nblk, N);
-    if (v4)
-        hipLaunchKernelGGL(k_in_bwd_stats<4>, grid, dim3(g.threads), sm, s, x, dy, gamma, beta, mean, rstd, partial, C,
-                           g.CG, g.R, V, g.chunk, slope);
-    else
-        hipLaunchKernelGGL(k_in_bwd_stats<1>, grid, dim3(g.threads), sm, s, x, dy, gamma, beta, mean, rstd, partial, C,
-                           g.CG, g.R, V, g.chunk, slope);
+    MVD_REQUIRE(v4 || !(xb || yb), "instnorm_bwd: bf16 I/O needs C %% 4 == 0");
+    if (v4) {
+        auto kern = xb ? (yb ? k_in_bwd_stats<4, true, true> : k_in_bwd_stats<4, true, false>)
+                       : (yb ? k_in_bwd_stats<4, false, true> : k_in_bwd_stats<4, false, false>);
+        hipLaunchKernelGGL(kern, grid, dim3(g.threads), sm, s, x, dy, gamma, beta, mean, rstd, partial, C, g.CG, g.R, V,
+                           g.chunk, slope);
+    } else
+        hipLaunchKernelGGL((k_in_bwd_stats<1, false, false>), grid, dim3(g.threads), sm, s, x, dy, gamma, beta, mean, rstd,
+                           partial, C, g.CG, g.R, V, g.chunk, slope);
     if (check_launch("instnorm bwd stats")) return 1;
     hipLaunchKernelGGL(k_in_bwd_finalize, dim3(C), dim3(64), 0, s, partial, sums, dgamma, dbeta, N, C,
                        g.nblk);
@@ -463,12 +473,39 @@ int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, 
         long cap2 = 8192 / N > 0 ? 8192 / N : 1;
         if (nb2 > cap2) nb2 = cap2;
         const long chunk2 = cdiv(V, nb2);
-        hipLaunchKernelGGL(k_in_bwd_apply_rows, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, s, x, dy, gamma, beta,
-                           mean, rstd, sums, dx, C, g.CG, g.R, V, chunk2, slope);
+        auto kern = xb ? (yb ? k_in_bwd_apply_rows<true, true> : k_in_bwd_apply_rows<true, false>)
+                       : (yb ? k_in_bwd_apply_rows<false, true> : k_in_bwd_apply_rows<false, false>);
+        hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, s, x, dy, gamma, beta, mean, rstd,
+                           sums, dx, C, g.CG, g.R, V, chunk2, slope);
     }
     else
         hipLaunchKernelGGL(k_in_bwd_apply<1>, dim3(bx, N), dim3(256), 0, s, x, dy, gamma, beta, mean, rstd, sums, dx, C,
                            V, slope);
     return check_launch("instnorm bwd apply");
+}
+
+int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                           int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes, void *stream) {
+    return in_fwd(x, false, gamma, beta, y, false, mean, rstd, N, V, C, eps, slope, ws, ws_bytes, stream);
+}
+
+int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, const float *beta, const float *mean,
+                           const float *rstd, float *dx, float *dgamma, float *dbeta, int N, long V, int C,
+                           float slope, void *ws, size_t ws_bytes, void *stream) {
+    return in_bwd(x, false, dy, false, gamma, beta, mean, rstd, dx, dgamma, dbeta, N, V, C, slope, ws, ws_bytes, stream);
+}
+
+int mvd_instnorm_lrelu_fwd_bf16(const void *x, int x_is_bf16, const float *gamma, const float *beta, uint16_t *y,
+                                float *mean, float *rstd, int N, long V, int C, float eps, float slope, void *ws,
+                                size_t ws_bytes, void *stream) {
+    return in_fwd(reinterpret_cast<const float *>(x), x_is_bf16 != 0, gamma, beta, reinterpret_cast<float *>(y), true, mean,
+                  rstd, N, V, C, eps, slope, ws, ws_bytes, stream);
+}
+
+int mvd_instnorm_lrelu_bwd_bf16(const void *x, int x_is_bf16, const uint16_t *dy, const float *gamma, const float *beta,
+                                const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta, int N,
+                                long V, int C, float slope, void *ws, size_t ws_bytes, void *stream) {
+    return in_bwd(reinterpret_cast<const float *>(x), x_is_bf16 != 0, reinterpret_cast<const float *>(dy), true, gamma, beta,
+                  mean, rstd, reinterpret_cast<float *>(dx), dgamma, dbeta, N, V, C, slope, ws, ws_bytes, stream);
 }
 }

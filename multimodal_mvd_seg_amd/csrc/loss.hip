@@ -9,6 +9,7 @@ constexpr int KLCMAX = 32; // channels of the KL softmax (logits <= 8, features 
 
 // =============================================================================================== seg head fwd
 // block: 256 threads = 64 voxels x 4 class slots; channels staged through LDS in chunks of 32 (coalesced 128-B rows)
+template <bool XB>
 __global__ void k_seghead_fwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                               float *__restrict__ logits, long V, int C, int K) {
     __shared__ float tile[64][33];
@@ -17,13 +18,13 @@ __global__ void k_seghead_fwd(const float *__restrict__ x, const float *__restri
     const int t = threadIdx.x;
     const int vox = t & 63, kq = t >> 6;
     float acc[2] = {0.f, 0.f};
-    const float *xn = x + (size_t)n * V * C;
+    const size_t xn = (size_t)n * V * C;
     for (int c0 = 0; c0 < C; c0 += 32) {
         __syncthreads();
         for (int j = t; j < 64 * 32; j += 256) {
             int vv = j >> 5, ch = j & 31;
             long v = v0 + vv;
-            tile[vv][ch] = (v < V && c0 + ch < C) ? xn[(size_t)v * C + c0 + ch] : 0.f;
+            tile[vv][ch] = (v < V && c0 + ch < C) ? ld1<XB>(x, xn + (size_t)v * C + c0 + ch) : 0.f;
         }
         __syncthreads();
         const int cn = (C - c0 < 32) ? (C - c0) : 32;
@@ -49,6 +50,7 @@ __global__ void k_seghead_fwd(const float *__restrict__ x, const float *__restri
 }
 
 // dx[n][v][c] (+)= sum_k dl[n][k][v] * w[k][c]
+template <bool XB>
 __global__ void k_seghead_dx(const float *__restrict__ dl, const float *__restrict__ w, float *__restrict__ dx, long V,
                              int C, int K, int accumulate) {
     extern __shared__ float sm[];  // w_s[K][C], dl_s[K][64]
@@ -64,17 +66,18 @@ __global__ void k_seghead_dx(const float *__restrict__ dl, const float *__restri
         dl_s[j] = (v < V) ? dl[((size_t)n * K + k) * V + v] : 0.f;
     }
     __syncthreads();
-    float *dxn = dx + ((size_t)n * V + v0) * C;
+    const size_t dxn = ((size_t)n * V + v0) * C;
     const long nv = (V - v0 < 64) ? (V - v0) : 64;
     for (long j = t; j < nv * C; j += 256) {
         int vv = (int)(j / C), c = (int)(j % C);
         float a = 0.f;
         for (int k = 0; k < K; k++) a += dl_s[k * 64 + vv] * w_s[k * C + c];
-        dxn[j] = accumulate ? dxn[j] + a : a;
+        st1<XB>(dx, dxn + j, accumulate ? ld1<XB>(dx, dxn + j) + a : a);
     }
 }
 
 // partial[b][k*C + c] = sum over the block's voxels of dl[k][v]*x[v][c]; partial[b][K*C + k] = sum dl[k][v]
+template <bool XB>
 __global__ void k_seghead_dw(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
                              int N, long V, int C, int K, long chunk) {
     __shared__ float xs[64][33];
@@ -94,7 +97,7 @@ __global__ void k_seghead_dw(const float *__restrict__ x, const float *__restric
             for (int j = t; j < 64 * 32; j += 256) {
                 int vv = j >> 5, ch = j & 31;
                 long g = base + vv;
-                xs[vv][ch] = (g < g1 && c0 + ch < C) ? x[(size_t)g * C + c0 + ch] : 0.f;
+                xs[vv][ch] = (g < g1 && c0 + ch < C) ? ld1<XB>(x, (size_t)g * C + c0 + ch) : 0.f;
             }
             for (int j = t; j < K * 64; j += 256) {
                 int k = j >> 6, vv = j & 63;
@@ -125,6 +128,7 @@ __global__ void k_seghead_dw(const float *__restrict__ x, const float *__restric
 
 // streaming variant for C % 4 == 0: thread = (4-channel group, row); each thread keeps K x 4 accumulators in
 // registers while walking its rows with float4 loads; rows are combined through LDS in a fixed order.
+template <bool XB>
 __global__ void k_seghead_dw4(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
                               int N, long V, int C, int K, long chunk) {
     extern __shared__ float smf[];  // [R][K*C + K]
@@ -146,7 +150,7 @@ __global__ void k_seghead_dw4(const float *__restrict__ x, const float *__restri
     if (r < R) {
         for (long i = g0 + r; i < g1; i += R) {
             const long n = i / V, v = i - n * V;
-            const float4 q = *reinterpret_cast<const float4 *>(x + (size_t)i * C + g * 4);
+            const float4 q = ld4<XB>(x, (size_t)i * C + g * 4);
 #pragma unroll
             for (int k = 0; k < KMAX; k++)
                 if (k < K) {
@@ -510,13 +514,21 @@ static inline long cap_per_n(long total_blocks, int N) {
 
 extern "C" {
 
-int mvd_seghead_fwd(const float *x, const float *w, const float *bias, float *logits, int N, long V, int C, int K,
-                    void *stream) {
+static int seghead_fwd_impl(const float *x, bool xb, const float *w, const float *bias, float *logits, int N, long V,
+                            int C, int K, void *stream) {
     MVD_REQUIRE(x && w && bias && logits, "seghead_fwd: null pointer");
     MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && K > 0 && K <= KMAX, "seghead_fwd: bad shape (K<=8)");
-    hipLaunchKernelGGL(k_seghead_fwd, dim3(cdiv(V, 64), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C,
-                       K);
+    auto kern = xb ? k_seghead_fwd<true> : k_seghead_fwd<false>;
+    hipLaunchKernelGGL(kern, dim3(cdiv(V, 64), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C, K);
     return check_launch("seghead_fwd");
+}
+int mvd_seghead_fwd(const float *x, const float *w, const float *bias, float *logits, int N, long V, int C, int K,
+                    void *stream) {
+    return seghead_fwd_impl(x, false, w, bias, logits, N, V, C, K, stream);
+}
+int mvd_seghead_fwd_bf16(const uint16_t *x, const float *w, const float *bias, float *logits, int N, long V, int C,
+                         int K, void *stream) {
+    return seghead_fwd_impl(reinterpret_cast<const float *>(x), true, w, bias, logits, N, V, C, K, stream);
 }
 
 static long seghead_chunk(long total, int *nblk) {
@@ -535,15 +547,17 @@ size_t mvd_seghead_bwd_workspace_bytes(int N, long V, int C, int K) {
     return (size_t)nblk * (K * C + K) * sizeof(double) + 256;
 }
 
-int mvd_seghead_bwd(const float *x, const float *w, const float *dlogits, float *dx, float *dw, float *dbias, int N,
-                    long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+static int seghead_bwd_impl(const float *x, bool xb, const float *w, const float *dlogits, float *dx, float *dw,
+                            float *dbias, int N, long V, int C, int K, int accumulate, void *ws, size_t ws_bytes,
+                            void *stream) {
     MVD_REQUIRE(x && w && dlogits && ws, "seghead_bwd: null pointer");
     MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && K > 0 && K <= KMAX, "seghead_bwd: bad shape (K<=8)");
     MVD_REQUIRE(ws_bytes >= mvd_seghead_bwd_workspace_bytes(N, V, C, K), "seghead_bwd: workspace too small");
     hipStream_t s = as_stream(stream);
     if (dx) {
         size_t sm = ((size_t)K * C + (size_t)K * 64) * sizeof(float);
-        hipLaunchKernelGGL(k_seghead_dx, dim3(cdiv(V, 64), N), dim3(256), sm, s, dlogits, w, dx, V, C, K, accumulate);
+        hipLaunchKernelGGL(xb ? k_seghead_dx<true> : k_seghead_dx<false>, dim3(cdiv(V, 64), N), dim3(256), sm, s, dlogits, w,
+                           dx, V, C, K, accumulate);
         if (check_launch("seghead_dx")) return 1;
     }
     if (dw) {
@@ -554,16 +568,27 @@ int mvd_seghead_bwd(const float *x, const float *w, const float *dlogits, float 
         const int CG = C / 4, R = (C % 4 == 0 && CG <= 256) ? 256 / CG : 0;
         const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
         if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0)
-            hipLaunchKernelGGL(k_seghead_dw4, dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s, x, dlogits, partial, N, V,
+            hipLaunchKernelGGL(xb ? k_seghead_dw4<true> : k_seghead_dw4<false>, dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s, x, dlogits, partial, N, V,
                                C, K, chunk);
         else
-            hipLaunchKernelGGL(k_seghead_dw, dim3(nblk), dim3(256), 0, s, x, dlogits, partial, N, V, C, K, chunk);
+            hipLaunchKernelGGL(xb ? k_seghead_dw<true> : k_seghead_dw<false>, dim3(nblk), dim3(256), 0, s, x, dlogits, partial,
+                               N, V, C, K, chunk);
         if (check_launch("seghead_dw")) return 1;
         // outputs [K*C] then [K]: dw and dbias are separate buffers -> two reduces over the same partials
         if (reduce_partials(partial, dw, nblk, K * C, s, K * C + K, 0)) return 1;
         if (reduce_partials(partial, dbias, nblk, K, s, K * C + K, K * C)) return 1;
     }
     return 0;
+}
+
+int mvd_seghead_bwd(const float *x, const float *w, const float *dlogits, float *dx, float *dw, float *dbias, int N,
+                    long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    return seghead_bwd_impl(x, false, w, dlogits, dx, dw, dbias, N, V, C, K, accumulate, ws, ws_bytes, stream);
+}
+int mvd_seghead_bwd_bf16(const uint16_t *x, const float *w, const float *dlogits, uint16_t *dx, float *dw, float *dbias,
+                         int N, long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    return seghead_bwd_impl(reinterpret_cast<const float *>(x), true, w, dlogits, reinterpret_cast<float *>(dx), dw, dbias,
+                            N, V, C, K, accumulate, ws, ws_bytes, stream);
 }
 
 size_t mvd_dcce_workspace_bytes(int N, long V, int K) {

@@ -72,11 +72,13 @@ class ConvDropoutNormReLU(nn.Module):
         nonlin_kwargs = dict(nonlin_kwargs or {'inplace': True})
         self.nonlin = (nonlin or nn.LeakyReLU)(**nonlin_kwargs)
         self.all_modules = nn.Sequential(self.conv, self.norm, self.nonlin)
+        self.precision = "fp32"  # "bf16": see set_precision()
 
     def forward(self, x, x2=None):
         y = self.conv(x, x2)
         slope = getattr(self.nonlin, 'negative_slope', 0.01)
-        return ops.InstanceNormLeakyReLUFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, slope)
+        return ops.InstanceNormLeakyReLUFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, slope,
+                                                 self.precision == "bf16")
 
     def compute_conv_feature_map_size(self, input_size):
         output_size = [i // j for i, j in zip(input_size, self.stride)]
@@ -258,6 +260,20 @@ class MI355PlainConvUNet(nn.Module):
     def compute_conv_feature_map_size(self, input_size):
         return self.encoder.compute_conv_feature_map_size(input_size) + \
             self.decoder.compute_conv_feature_map_size(input_size)
+
+
+def set_precision(module: nn.Module, precision: str):
+    """Mixed precision of the reference's autocast path (nnUNetTrainer.py:906; BASELINE cfg 4/5), MI355X style:
+    "bf16" makes every fused InstanceNorm+LeakyReLU emit bf16, so every conv / transposed conv / seg head after the
+    first one reads bf16 activations and runs on the bf16 MFMA engine (fp32 accumulate).  Parameters, the 4-modality
+    input conv, normalisation statistics, logits, losses, weight gradients and the optimizer stay fp32 -- bf16 has
+    fp32's exponent range, so there is no GradScaler (the reference needs one for fp16, nnUNetTrainer.py:916-920)."""
+    if precision not in ("fp32", "bf16"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+    for m in module.modules():
+        if isinstance(m, ConvDropoutNormReLU):
+            m.precision = precision
+    return module
 
 
 PlainConvUNet = MI355PlainConvUNet  # the name get_network_from_plans.py:35 maps 'PlainConvUNet' to

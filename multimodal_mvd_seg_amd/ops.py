@@ -29,9 +29,9 @@ def _require_cuda(*ts):
         if t is not None and not t.is_cuda:
             raise RuntimeError("multimodal_mvd_seg_amd ops need tensors on the MI355X (cuda) device; "
                                "there is no CPU fallback")
-        if t is not None and t.dtype != torch.float32 and t.dtype not in (torch.uint8, torch.int32, torch.int64,
-                                                                          torch.int16):
-            raise RuntimeError(f"unsupported dtype {t.dtype} (this round's kernels compute in fp32)")
+        if t is not None and t.dtype not in (torch.float32, torch.bfloat16, torch.uint8, torch.int32, torch.int64,
+                                             torch.int16):
+            raise RuntimeError(f"unsupported dtype {t.dtype} (kernels take fp32, or bf16 activations in mixed precision)")
 
 
 class _Workspace:
@@ -52,8 +52,15 @@ def _is_cl3d(t):
     return t.dim() == 5 and t.is_contiguous(memory_format=CL3D)
 
 
-def empty_cl3d(shape, device):
-    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=CL3D)
+def empty_cl3d(shape, device, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=device, memory_format=CL3D)
+
+
+BF16 = torch.bfloat16
+
+
+def _is_bf16(t):
+    return t is not None and t.dtype == BF16
 
 
 def to_ndhwc(t):
@@ -61,6 +68,9 @@ def to_ndhwc(t):
     _require_cuda(t)
     if _is_cl3d(t):
         return t
+    if t.dtype == BF16:
+        # bf16 activations are produced NDHWC by these ops; a planar one can only come from outside the path
+        raise RuntimeError("bf16 activations must already be NDHWC (torch.channels_last_3d)")
     if not t.is_contiguous():
         t = t.contiguous()
     N, C = t.shape[:2]
@@ -100,6 +110,22 @@ def pack_weight(weight, transposed):
     return wf, wb
 
 
+def pack_weight_bf16(weight, transposed):
+    """fp32 master weight -> bf16 (wf16, wb16) in the MFMA 32x32x16 operand layout (mvd_pack_weight_bf16)."""
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    if transposed:
+        C, K = w.shape[:2]
+    else:
+        K, C = w.shape[:2]
+    T = w[0, 0].numel()
+    wf = torch.empty((T * C * K,), dtype=BF16, device=w.device)
+    wb = torch.empty((T * C * K,), dtype=BF16, device=w.device)
+    call("mvd_pack_weight_bf16", _p(w), _p(wf), _p(wb), K, C, T, 1 if transposed else 0, _stream())
+    return wf, wb
+
+
 def _out_dim(i, k, s):
     return (i + 2 * ((k - 1) // 2) - k) // s + 1
 
@@ -122,12 +148,16 @@ class Conv3dFn(Function):
             raise RuntimeError(f"conv3d: weight expects {C} input channels, got {C1}+{C2}")
         if x2 is not None and tuple(x2.shape[2:]) != (D, H, W):
             raise RuntimeError("conv3d: the two concatenated inputs differ in spatial size")
-        wf, wb = pack_weight(weight, False)
+        bf = _is_bf16(x1)
+        if x2 is not None and _is_bf16(x2) != bf:
+            raise RuntimeError("conv3d: the two concatenated inputs differ in dtype")
+        wf, wb = pack_weight_bf16(weight, False) if bf else pack_weight(weight, False)
         od = [_out_dim(i, k, s) for i, k, s in zip((D, H, W), ks, stride)]
-        y = empty_cl3d((N, K, *od), x1.device)
+        y = empty_cl3d((N, K, *od), x1.device, x1.dtype)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, od[0] * od[1] * od[2], K), x1.device)
-        call("mvd_conv3d_fwd", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
-             _p(ws), ws.numel(), _stream())
+        call("mvd_conv3d_fwd_bf16" if bf else "mvd_conv3d_fwd", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H,
+             W, K, i3(ks), i3(stride), _p(ws), ws.numel(), _stream())
+        ctx.bf = bf
         ctx.save_for_backward(x1, x2, wb)
         ctx.geom = (N, C1, C2, D, H, W, K, ks, tuple(stride), tuple(od), bias is not None)
         return y
@@ -139,13 +169,14 @@ class Conv3dFn(Function):
         N, C1, C2, D, H, W, K, ks, stride, od, has_bias = ctx.geom
         dy = to_ndhwc(dy)
         dev = dy.device
+        sfx = "_bf16" if ctx.bf else ""
         dx1 = dx2 = dw = db = None
         need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
         if need1 or need2:
-            dx1 = empty_cl3d((N, C1, D, H, W), dev)
-            dx2 = empty_cl3d((N, C2, D, H, W), dev) if x2 is not None else None
+            dx1 = empty_cl3d((N, C1, D, H, W), dev, dy.dtype)
+            dx2 = empty_cl3d((N, C2, D, H, W), dev, dy.dtype) if x2 is not None else None
             ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C1 + C2), dev)
-            call("mvd_conv3d_dgrad", _p(dy), _p(wb), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks), i3(stride),
+            call("mvd_conv3d_dgrad" + sfx, _p(dy), _p(wb), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks), i3(stride),
                  _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[2]:
             T = ks[0] * ks[1] * ks[2]
@@ -153,7 +184,7 @@ class Conv3dFn(Function):
             db = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
             nb = query("mvd_conv3d_wgrad_workspace_bytes", C1 + C2, K, T, N, *od)
             ws = _Workspace.get(nb, dev)
-            call("mvd_conv3d_wgrad", _p(x1), C1, _p(x2), C2, _p(dy), _p(dw), _p(db), N, D, H, W, K, i3(ks), i3(stride),
+            call("mvd_conv3d_wgrad" + sfx, _p(x1), C1, _p(x2), C2, _p(dy), _p(dw), _p(db), N, D, H, W, K, i3(ks), i3(stride),
                  _p(ws), ws.numel(), _stream())
         return (dx1 if need1 else None), (dx2 if need2 else None), dw, db, None
 
@@ -171,10 +202,12 @@ class ConvTranspose3dFn(Function):
         N, Cx, D, H, W = x.shape
         if Cx != C:
             raise RuntimeError("convT3d: channel mismatch")
-        wf, wb = pack_weight(weight, True)
-        y = empty_cl3d((N, K, D * stride[0], H * stride[1], W * stride[2]), x.device)
+        bf = _is_bf16(x)
+        wf, wb = pack_weight_bf16(weight, True) if bf else pack_weight(weight, True)
+        y = empty_cl3d((N, K, D * stride[0], H * stride[1], W * stride[2]), x.device, x.dtype)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K), x.device)
-        call("mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
+        ctx.bf = bf
+        call("mvd_convT3d_fwd_bf16" if bf else "mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
              _stream())
         ctx.save_for_backward(x, wb)
         ctx.geom = (N, C, K, D, H, W, tuple(stride), bias is not None)
@@ -188,10 +221,11 @@ class ConvTranspose3dFn(Function):
         dy = to_ndhwc(dy)
         dev = dy.device
         dx = dw = db = None
+        sfx = "_bf16" if ctx.bf else ""
         if ctx.needs_input_grad[0]:
-            dx = empty_cl3d((N, C, D, H, W), dev)
+            dx = empty_cl3d((N, C, D, H, W), dev, dy.dtype)
             ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C), dev)
-            call("mvd_convT3d_dgrad", _p(dy), _p(wb), _p(dx), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
+            call("mvd_convT3d_dgrad" + sfx, _p(dy), _p(wb), _p(dx), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
                  _stream())
         if ctx.needs_input_grad[1]:
             T = stride[0] * stride[1] * stride[2]
@@ -199,7 +233,7 @@ class ConvTranspose3dFn(Function):
             db = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
             nb = query("mvd_convT3d_wgrad_workspace_bytes", C, K, T, N, D, H, W)
             ws = _Workspace.get(nb, dev)
-            call("mvd_convT3d_wgrad", _p(x), _p(dy), _p(dw), _p(db), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
+            call("mvd_convT3d_wgrad" + sfx, _p(x), _p(dy), _p(dw), _p(db), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
                  _stream())
         return dx, dw, db, None
 
@@ -209,21 +243,28 @@ class InstanceNormLeakyReLUFn(Function):
     """InstanceNorm3d(eps, affine) + LeakyReLU(slope) fused (get_network_from_plans.py:41-44)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, slope):
+    def forward(ctx, x, gamma, beta, eps, slope, out_bf16=False):
         _require_cuda(x, gamma, beta)
         x = to_ndhwc(x)
         N, C = x.shape[:2]
         V = x[0, 0].numel()
-        y = empty_cl3d(x.shape, x.device)
+        xb = _is_bf16(x)
+        yb = bool(out_bf16) or xb  # a bf16 input never widens again inside the network
+        y = empty_cl3d(x.shape, x.device, BF16 if yb else torch.float32)
         mean = torch.empty((N, C), dtype=torch.float32, device=x.device)
         rstd = torch.empty((N, C), dtype=torch.float32, device=x.device)
         nb = query("mvd_instnorm_workspace_bytes", N, V, C)
         ws = _Workspace.get(nb, x.device)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        call("mvd_instnorm_lrelu_fwd", _p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V, C, float(eps), float(slope),
-             _p(ws), ws.numel(), _stream())
+        if yb:
+            call("mvd_instnorm_lrelu_fwd_bf16", _p(x), int(xb), _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V, C,
+                 float(eps), float(slope), _p(ws), ws.numel(), _stream())
+        else:
+            call("mvd_instnorm_lrelu_fwd", _p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V, C, float(eps),
+                 float(slope), _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(x, g, b, mean, rstd)
         ctx.slope = float(slope)
+        ctx.yb = yb
         return y
 
     @staticmethod
@@ -233,14 +274,18 @@ class InstanceNormLeakyReLUFn(Function):
         dy = to_ndhwc(dy)
         N, C = x.shape[:2]
         V = x[0, 0].numel()
-        dx = empty_cl3d(x.shape, x.device)
+        dx = empty_cl3d(x.shape, x.device, x.dtype)
         dg = torch.empty((C,), dtype=torch.float32, device=x.device)
         db = torch.empty((C,), dtype=torch.float32, device=x.device)
         nb = query("mvd_instnorm_workspace_bytes", N, V, C)
         ws = _Workspace.get(nb, x.device)
-        call("mvd_instnorm_lrelu_bwd", _p(x), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), N, V, C,
-             ctx.slope, _p(ws), ws.numel(), _stream())
-        return dx, dg, db, None, None
+        if ctx.yb:
+            call("mvd_instnorm_lrelu_bwd_bf16", _p(x), int(_is_bf16(x)), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx),
+                 _p(dg), _p(db), N, V, C, ctx.slope, _p(ws), ws.numel(), _stream())
+        else:
+            call("mvd_instnorm_lrelu_bwd", _p(x), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), N, V,
+                 C, ctx.slope, _p(ws), ws.numel(), _stream())
+        return dx, dg, db, None, None, None
 
 
 # ======================================================================================================== seg head
@@ -256,7 +301,8 @@ class SegHeadFn(Function):
         V = x[0, 0].numel()
         w = weight.detach().reshape(K, C).contiguous()
         logits = torch.empty((N, K, *x.shape[2:]), dtype=torch.float32, device=x.device)
-        call("mvd_seghead_fwd", _p(x), _p(w), _p(bias), _p(logits), N, V, C, K, _stream())
+        call("mvd_seghead_fwd_bf16" if _is_bf16(x) else "mvd_seghead_fwd", _p(x), _p(w), _p(bias), _p(logits), N, V, C, K,
+             _stream())
         ctx.save_for_backward(x, w)
         ctx.wshape = tuple(weight.shape)
         return logits
@@ -270,13 +316,41 @@ class SegHeadFn(Function):
         V = x[0, 0].numel()
         dl = dl.contiguous()
         dev = x.device
-        dx = empty_cl3d(x.shape, dev) if ctx.needs_input_grad[0] else None
+        dx = empty_cl3d(x.shape, dev, x.dtype) if ctx.needs_input_grad[0] else None
         dw = torch.empty((K, C), dtype=torch.float32, device=dev)
         db = torch.empty((K,), dtype=torch.float32, device=dev)
         nb = query("mvd_seghead_bwd_workspace_bytes", N, V, C, K)
         ws = _Workspace.get(nb, dev)
-        call("mvd_seghead_bwd", _p(x), _p(w), _p(dl), _p(dx), _p(dw), _p(db), N, V, C, K, 0, _p(ws), ws.numel(), _stream())
+        call("mvd_seghead_bwd_bf16" if _is_bf16(x) else "mvd_seghead_bwd", _p(x), _p(w), _p(dl), _p(dx), _p(dw), _p(db), N, V, C, K, 0, _p(ws), ws.numel(), _stream())
         return dx, dw.view(ctx.wshape), db
+
+
+class CastFn(Function):
+    """Precision boundary: bf16 activation -> fp32 (and the fp32 gradient back to bf16), layout preserved.  Used where
+    a bf16 feature map feeds an fp32 loss kernel (the distillation features)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        if not _is_bf16(x):
+            raise RuntimeError("CastFn widens bf16 tensors")
+        x = to_ndhwc(x)
+        y = torch.empty_like(x, dtype=torch.float32)  # preserves the NDHWC strides
+        call("mvd_cast_bf16_to_f32", _p(x), _p(y), x.numel(), _stream())
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = to_ndhwc(dy)
+        dx = torch.empty_like(dy, dtype=BF16)
+        call("mvd_cast_f32_to_bf16", _p(dy), _p(dx), dy.numel(), _stream())
+        return dx
+
+
+def widen(x):
+    """fp32 view of an activation for the fp32 loss kernels (identity in the fp32 mode)."""
+    return CastFn.apply(x) if _is_bf16(x) else x
 
 
 # ======================================================================================================== losses

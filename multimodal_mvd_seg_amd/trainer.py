@@ -20,7 +20,7 @@ import torch.distributed as dist
 from torch import nn
 
 from . import losses, ops
-from .network import InitWeights_He, MI355PlainConvUNet, MVDDualBranchNet
+from .network import InitWeights_He, MI355PlainConvUNet, MVDDualBranchNet, set_precision
 from .optim import FlatParams, FusedSGDNesterov, PolyLRScheduler
 from .parallel import BucketedGradReducer, broadcast_parameters, ddp_batch_split
 
@@ -145,6 +145,9 @@ class nnUNetTrainerMI355(object):
         self.network = None
         self.optimizer = self.lr_scheduler = None
         self.grad_scaler = None  # fp32 path (the reference's CPU branch: no autocast, no GradScaler, :906,:921-924)
+        # "bf16": the reference's autocast path (:906) restated for MI355X -- bf16 activations on the bf16 MFMA engine,
+        # fp32 master weights / statistics / losses / optimizer, no GradScaler (network.set_precision)
+        self.precision = 'fp32'
         self.loss = None
         self.reducer = None
         self.was_initialized = False
@@ -166,6 +169,7 @@ class nnUNetTrainerMI355(object):
         self.network = self.build_network_architecture(self.plans_manager, self.dataset_json,
                                                        self.configuration_manager, self.num_input_channels,
                                                        self.enable_deep_supervision).to(self.device)
+        set_precision(self.network, self.precision)
         self.optimizer, self.lr_scheduler = self.configure_optimizers()
         if self.is_ddp:
             # DDP(network): broadcast rank 0's weights, then reduce gradients bucket-wise during backward (:220-222)
@@ -317,6 +321,7 @@ class ContrastiveTrainerMI355(nnUNetTrainerMI355):
         tgt0 = target[0] if isinstance(target, (list, tuple)) else target
         mutual = losses.kl_loss_compute1(top1[:, v], top2[:, v], self.kl_T)
         if self.feat_kl:
+            f1, f2 = ops.widen(f1), ops.widen(f2)  # bf16 feature maps cross into the fp32 KL kernel
             mutual = mutual + losses.l2_loss(f1, f2, channel_wise=True, T=self.kl_T)
         l = l + self.lambda1 * mutual
         if self.use_topo:

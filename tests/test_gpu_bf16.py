@@ -2,6 +2,7 @@
 bf16-rounded inputs and weights (products of bf16 numbers are exact in fp32, accumulation is fp32), rounded to bf16 --
 so the only legitimate difference is the accumulation order and the final rounding: 1 bf16 ulp (2^-8 relative)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -65,7 +66,8 @@ def test_conv3d_bf16_fwd_dgrad(C1, C2, K, sp, stride, N):
     ws = torch.empty(max(1024, query("mvd_conv_fwd_workspace_bytes", N, sp[0] * sp[1] * sp[2], max(K, C1 + C2))),
                      dtype=torch.uint8, device=DEV)
     D, H, W = sp
-    call("mvd_conv3d_fwd_bf16", _p(d1), C1, _p(d2), C2, _p(wf), _p(b.to(DEV)), _p(y), N, D, H, W, K, i3((3, 3, 3)), i3(st),
+    bd = b.to(DEV)
+    call("mvd_conv3d_fwd_bf16", _p(d1), C1, _p(d2), C2, _p(wf), _p(bd), _p(y), N, D, H, W, K, i3((3, 3, 3)), i3(st),
          _p(ws), ws.numel(), _stream())
     close_bf16(y, ref.detach(), "y")
     gyd = gy.to(DEV).contiguous(memory_format=cl)
@@ -93,12 +95,14 @@ def test_convT3d_bf16_fwd_dgrad(C, K, sp, N):
     xd = x.to(DEV).contiguous(memory_format=cl)
     wf = torch.empty(8 * C * K, dtype=torch.bfloat16, device=DEV)
     wb = torch.empty(8 * C * K, dtype=torch.bfloat16, device=DEV)
-    call("mvd_pack_weight_bf16", _p(w.to(DEV).contiguous()), _p(wf), _p(wb), K, C, 8, 1, _stream())
+    wd = w.to(DEV).contiguous()
+    call("mvd_pack_weight_bf16", _p(wd), _p(wf), _p(wb), K, C, 8, 1, _stream())
     D, H, W = sp
     y = torch.empty((N, K, 2 * D, 2 * H, 2 * W), dtype=torch.bfloat16, device=DEV).contiguous(memory_format=cl)
     ws = torch.empty(max(1024, query("mvd_conv_fwd_workspace_bytes", N, D * H * W, max(C, K))), dtype=torch.uint8,
                      device=DEV)
-    call("mvd_convT3d_fwd_bf16", _p(xd), _p(wf), _p(b.to(DEV)), _p(y), N, D, H, W, C, K, i3((2, 2, 2)), _p(ws), ws.numel(),
+    bd = b.to(DEV)
+    call("mvd_convT3d_fwd_bf16", _p(xd), _p(wf), _p(bd), _p(y), N, D, H, W, C, K, i3((2, 2, 2)), _p(ws), ws.numel(),
          _stream())
     close_bf16(y, ref.detach(), "y")
     dx = torch.empty_like(xd)
@@ -171,3 +175,123 @@ def test_convT3d_bf16_wgrad(C, K, sp, N):
          _stream())
     close_f32(dw, w.grad, "dw")
     close_f32(db, b.grad, "dbias")
+
+
+@pytest.mark.parametrize("xb", [False, True])
+@pytest.mark.parametrize("N,C,sp", [(2, 32, (8, 8, 8)), (1, 64, (6, 5, 7)), (2, 320, (2, 2, 2))])
+def test_instnorm_lrelu_bf16_io(N, C, sp, xb):
+    """fp32-or-bf16 conv output -> bf16 activation; statistics/arithmetic as the fp32 kernel, so against fp64 on the
+    same (rounded) input the output is 1 bf16 ulp and dgamma/dbeta are fp32-accurate; dx has x's dtype."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(N * C + int(xb))
+    x = torch.randn(N, C, *sp, generator=g) * 0.7 + 0.2
+    if xb:
+        x = bf(x)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    gy = bf(torch.randn(N, C, *sp, generator=g))
+    xr, gr, br = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    ref = F.leaky_relu(F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5), 0.01)
+    ref.backward(gy.double())
+    cl = torch.channels_last_3d
+    gx = x.to(DEV).contiguous(memory_format=cl).requires_grad_()
+    gg, gb = gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    y = ops.InstanceNormLeakyReLUFn.apply(gx, gg, gb, 1e-5, 0.01, True)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=cl)
+    close_bf16(y.detach(), ref.detach(), "y")
+    y.backward(gy.to(DEV).contiguous(memory_format=cl))
+    assert gx.grad.dtype == x.dtype
+    if xb:
+        close_bf16(gx.grad, xr.grad, "dx")
+    else:
+        close_f32(gx.grad, xr.grad, "dx")
+    close_f32(gg.grad, gr.grad, "dgamma")
+    close_f32(gb.grad, br.grad, "dbeta")
+
+
+def test_seghead_bf16_input():
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, C, K, sp = 2, 32, 5, (6, 7, 9)
+    x = bf(torch.randn(N, C, *sp, generator=g))
+    w = torch.randn(K, C, 1, 1, 1, generator=g) * 0.2
+    b = torch.randn(K, generator=g) * 0.1
+    gl = torch.randn(N, K, *sp, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.conv3d(xr, wr, br)
+    ref.backward(gl.double())
+    gx = x.to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_()
+    gw, gb = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.SegHeadFn.apply(gx, gw, gb)
+    assert y.dtype == torch.float32 and y.is_contiguous()
+    close_f32(y.detach(), ref.detach(), "logits")
+    y.backward(gl.to(DEV))
+    assert gx.grad.dtype == torch.bfloat16
+    close_bf16(gx.grad, xr.grad, "dx")
+    close_f32(gw.grad, wr.grad, "dw")
+    close_f32(gb.grad, br.grad, "db")
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1027, 32 * 33 * 35])
+def test_cast_bit_exact(n):
+    """round-to-nearest-even fp32 -> bf16 and exact widening, against torch's own conversion"""
+    from multimodal_mvd_seg_amd._lib import call
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g) * 10 ** torch.randint(-6, 6, (n,), generator=g).float()).to(DEV)
+    h = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    call("mvd_cast_f32_to_bf16", _p(x), _p(h), n, _stream())
+    assert torch.equal(h, x.to(torch.bfloat16))
+    back = torch.empty(n, device=DEV)
+    call("mvd_cast_bf16_to_f32", _p(h), _p(back), n, _stream())
+    assert torch.equal(back, h.float())
+
+
+def test_unet_bf16_step_no_worse_than_torch_autocast():
+    """Whole-network bar for the mixed-precision mode: against the fp64 evaluation of the same 4-stage network, the
+    HIP bf16 step must be at least as accurate as the reference's own mixed-precision recipe (torch autocast, here
+    CPU bf16: nnUNetTrainer.py:906 with dtype bf16) -- logits, loss and per-parameter gradients."""
+    import copy
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _cfg2_pair
+    from multimodal_mvd_seg_amd.network import set_precision
+    ora, loss_fn, batch, tr = _cfg2_pair(32, batch_size=2, n_stages=4)
+    ora64 = copy.deepcopy(ora).double()
+    out64 = ora64(batch["data"].double())
+    l64 = loss_fn(out64, [t.double() for t in batch["target"]])
+    l64.backward()
+    g64 = {n: p.grad for n, p in ora64.named_parameters()}
+    oac = copy.deepcopy(ora)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out_ac = oac(batch["data"])
+        l_ac = loss_fn(out_ac, batch["target"])
+    l_ac.backward()
+    g_ac = {n: p.grad for n, p in oac.named_parameters()}
+    set_precision(tr.network, "bf16")
+    tr.optimizer.zero_grad()
+    out = tr.network(batch["data"].to(DEV))
+    l = tr.loss(out, [t.to(DEV) for t in batch["target"]])
+    l.backward()
+    assert all(o.dtype == torch.float32 for o in out)
+    for o, a, r in zip(out, out_ac, out64):
+        r = r.detach()
+        e_hip = float((o.detach().cpu().double() - r).abs().max())
+        e_ac = float((a.detach().double() - r).abs().max())
+        assert e_hip <= 1.5 * e_ac + 1e-3 * float(r.abs().max()), f"logits: hip {e_hip:.3e} autocast {e_ac:.3e}"
+    assert abs(float(l) - float(l64)) <= max(2 * abs(float(l_ac) - float(l64)), 2e-3 * abs(float(l64)))
+    rel_hip, rel_ac = [], []
+    for n, p in tr.network.named_parameters():
+        r = g64[n]
+        nr = float(r.norm())
+        if nr < 1e-12:
+            continue
+        assert p.grad.dtype == torch.float32
+        rel_hip.append(float((p.grad.cpu().double() - r).norm()) / nr)
+        rel_ac.append(float((g_ac[n].double() - r).norm()) / nr)
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+    assert med(rel_hip) <= 1.25 * med(rel_ac), f"median grad relL2: hip {med(rel_hip):.3e} autocast {med(rel_ac):.3e}"
+    assert max(rel_hip) <= 1.5 * max(rel_ac), f"worst grad relL2: hip {max(rel_hip):.3e} autocast {max(rel_ac):.3e}"
+    # and one full optimizer step runs (clip + SGD on the fp32 master weights)
+    tr.on_train_epoch_start()
+    res = tr.train_step({"data": batch["data"].to(DEV), "target": [t.to(DEV) for t in batch["target"]]})
+    assert np.isfinite(float(res["loss"]))
