@@ -977,6 +977,171 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallc(const WgradGeom g, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 wgrad
+// bf16 A / B in HBM, bf16 MFMA (v_mfma_f32_32x32x16_bf16: 16 voxels per instruction), fp32 accumulate / partials.
+// The reduce dimension of the weight gradient is the VOXEL index, but NDHWC tiles are channel-contiguous: the LDS
+// images stay [slot][32 channels] (64-B rows, filled with plain 16-B stores) and the operands are fetched with gfx950's
+// transposing LDS read ds_read_b64_tr_b16: per 16-lane group a 4-voxel x 16-channel block comes back channel-major,
+// i.e. exactly the A (rows = reduce channels) / B (columns = produce channels) fragment of the MFMA -- two reads per
+// operand per 16-voxel step.  Four consecutive 64-B rows cover all 64 banks once: the reads are conflict-free for
+// unit-stride taps (2-way for the stride-2 side of strided / transposed convs).
+// NA / NB: uint4 (8 channels) per thread of the A halo / B tile.  Same split-K / prefetch structure as k_wgrad_mfma.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+
+__device__ inline bf16x8w tr_operand(const unsigned char *p0, const unsigned char *p1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p1);
+    return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int TPW, int NA, int NB, int SH>
+__global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgTile tg,
+                                                    const unsigned short *__restrict__ a1,
+                                                    const unsigned short *__restrict__ a2,
+                                                    const unsigned short *__restrict__ b, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    unsigned char *As = lds8;
+    unsigned char *Bs = lds8 + (size_t)NA * 4096;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y / tg.nkb, kb = blockIdx.y % tg.nkb;
+    const int split = blockIdx.x;
+    const int C = g.C1 + g.C2, K = g.K;
+
+    int ta[TPW], tb[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        ta[j] = tb[j] = 0;
+#pragma unroll
+        for (int t = 0; t < 27; t++)
+            if (t == wave + 4 * j && t < g.ntaps) {
+                ta[j] = tg.toffA[t];
+                tb[j] = tg.toffB[t];
+            }
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    const int c0 = cb * 32;
+    const unsigned short *asrc;
+    int Cs, cofs;
+    if (c0 < g.C1) {
+        asrc = a1; Cs = g.C1; cofs = c0;
+    } else {
+        asrc = a2; Cs = g.C2; cofs = c0 - g.C1;
+    }
+    const int k0 = kb * 32;
+    const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
+    const int TV = tg.TD * tg.TH * tg.TW;
+    const int na = tg.nslotsA * 4, nb = tg.nslotsB * 4;
+    const int part = tid & 3;
+
+    uint4 ra[NA], rb[NB];
+    auto load_tile = [&](int tile) {
+        unsigned r_ = (unsigned)tile;
+        const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+        const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+        const int td_ = (int)(r_ % (unsigned)tg.ntd);
+        const int n = (int)(r_ / (unsigned)tg.ntd);
+        const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
+        {
+            const int z0 = od0 * g.sa[0] + tg.minA[0], y0 = oh0 * g.sa[1] + tg.minA[1], x0 = ow0 * g.sa[2] + tg.minA[2];
+#pragma unroll
+            for (int u = 0; u < NA; u++) {
+                const int idx = u * 256 + tid;
+                const int slot = idx >> 2;
+                const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
+                const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
+                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                ra[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (idx < na && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                    ra[u] = *reinterpret_cast<const uint4 *>(
+                        asrc + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 8);
+            }
+        }
+        {
+            const int z0 = od0 * g.sb[0] + tg.minB[0], y0 = oh0 * g.sb[1] + tg.minB[1], x0 = ow0 * g.sb[2] + tg.minB[2];
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int idx = u * 256 + tid;
+                const int slot = idx >> 2;
+                const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
+                const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
+                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                rb[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (idx < nb && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
+                    rb[u] = *reinterpret_cast<const uint4 *>(
+                        b + ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 8);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NA; u++) *reinterpret_cast<uint4 *>(As + (size_t)(u * 256 + tid) * 16) = ra[u];
+#pragma unroll
+        for (int u = 0; u < NB; u++) *reinterpret_cast<uint4 *>(Bs + (size_t)(u * 256 + tid) * 16) = rb[u];
+    };
+    // transposed-read lane roles: 16-lane group gg = lane >> 4 takes channels 16*(gg&1).. of the voxels of k-half h;
+    // lane 4q+p of the group supplies the address of voxel row q, channel columns 4p..4p+3 (8 bytes)
+    const int q4 = (lane & 15) >> 2;
+    const int colb = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    int aoff[TPW], boff[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        aoff[j] = ta[j] * 64 + colb;
+        boff[j] = tb[j] * 64 + colb;
+    }
+    constexpr int NAV = SH == 2 ? 1 : TPW, NBV = SH == 1 ? 1 : TPW;
+
+    int tile = split;
+    if (tile < tg.ntiles) load_tile(tile);
+    while (tile < tg.ntiles) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        const int next = tile + tg.nsplit;
+        if (next < tg.ntiles) load_tile(next);
+        for (int s16 = 0; s16 < TV; s16 += 16) {  // TV is a multiple of 16 for every tile shape
+            int sa_[2], sb_[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int v = s16 + 8 * h + 4 * r + q4;
+                const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
+                sa_[r] = (((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2]) * 64;
+                sb_[r] = (((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2]) * 64;
+            }
+            bf16x8w av[NAV], bv[NBV];
+#pragma unroll
+            for (int j = 0; j < NAV; j++) av[j] = tr_operand(As + sa_[0] + aoff[j], As + sa_[1] + aoff[j]);
+#pragma unroll
+            for (int j = 0; j < NBV; j++) bv[j] = tr_operand(Bs + sb_[0] + boff[j], Bs + sb_[1] + boff[j]);
+#pragma unroll
+            for (int j = 0; j < TPW; j++)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[SH == 2 ? 0 : j], bv[SH == 1 ? 0 : j], acc[j], 0, 0, 0);
+        }
+        tile = next;
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        const int t = wave + 4 * j;
+        if (t < g.ntaps) {
+            float *po = partial + ((size_t)split * g.ntaps + t) * C * K;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
+            }
+        }
+    }
+}
+
 // dw[torch layout] = sum_split partial[split][t][c][k]   (fp32 partials, fp64 sum, fixed order)
 __global__ void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial, float *__restrict__ dw, int nsplit) {
     const int C = g.C1 + g.C2, K = g.K;
@@ -992,10 +1157,12 @@ __global__ void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial,
     dw[o] = (float)s;
 }
 
-static int wgrad_max_split(const WgradGeom &g) {
+static int wgrad_max_split(const WgradGeom &g, int per_cu = 2) {
     const int C = g.C1 + g.C2;
     const int ncb = (C + 31) / 32, nkb = (g.K + 31) / 32;
-    long ns = 256 / ((long)ncb * nkb);  // one workgroup per CU (register budget of the prefetching kernel)
+    // workgroups per CU: 1 for the fp32 kernel (register budget of its prefetch), 2 for the bf16 kernel; the
+    // workspace query sizes for 2
+    long ns = 256L * per_cu / ((long)ncb * nkb);
     if (ns < 1) ns = 1;
     const long per = (long)g.ntaps * C * g.K * 4;
     long cap = (256L << 20) / per;
@@ -1048,7 +1215,10 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         }
         const int nA = EA[0] * EA[1] * EA[2], nB = EB[0] * EB[1] * EB[2];
         int c = -1;
-        if (nA * 8 <= 13 * 256 && nB * 8 <= 4 * 256) c = 0;
+        if (bf16_in) {  // k_wgrad16: 64 slots per uint4-per-thread; (NA, NB) = (7, 2) or (1, 8)
+            if (nA <= 7 * 64 && nB <= 2 * 64) c = 0;
+            else if (nA <= 1 * 64 && nB <= 8 * 64) c = 1;
+        } else if (nA * 8 <= 13 * 256 && nB * 8 <= 4 * 256) c = 0;
         else if (nA * 8 <= 2 * 256 && nB * 8 <= 16 * 256) c = 1;
         if (c < 0) continue;
         cfg = c;
@@ -1067,7 +1237,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
             return m;
         };
         const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
-        const int nmaxA = (cfg == 0 ? 13 : 2) * 32, nmaxB = (cfg == 0 ? 4 : 16) * 32;
+        const int nmaxA = bf16_in ? (cfg == 0 ? 7 : 1) * 64 : (cfg == 0 ? 13 : 2) * 32;
+        const int nmaxB = bf16_in ? (cfg == 0 ? 2 : 8) * 64 : (cfg == 0 ? 4 : 16) * 32;
         tg.magAhw = magic(EAhw, nmaxA); tg.magAw = magic(tg.EAw, EAhw);
         tg.magBhw = magic(EBhw, nmaxB); tg.magBw = magic(tg.EBw, EBhw);
         if (tg.magAhw < 0 || tg.magAw < 0 || tg.magBhw < 0 || tg.magBw < 0) return -1;
@@ -1088,7 +1259,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     tg.ntiles = (int)ntiles;
     const int ncb = (C + 31) / 32;
     tg.nkb = (g.K + 31) / 32;
-    long ns = wgrad_max_split(g);
+    long ns = wgrad_max_split(g, bf16_in ? 2 : 1);
     if (ns > ntiles) ns = ntiles;
     tg.nsplit = (int)ns;
     const size_t need_ws = (size_t)tg.nsplit * g.ntaps * C * g.K * sizeof(float);
@@ -1120,7 +1291,34 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         sameA = sameA && tg.toffA[t] == tg.toffA[0];
         sameB = sameB && tg.toffB[t] == tg.toffB[0];
     }
-    if (!bf16_in && cfg == 0 && sameB && g.C2 == 0 && C <= 8 && C % 4 == 0 && g.ntaps * C <= 128 && tg.nslotsA * (C / 4) <= 2 * 256) {
+    if (bf16_in) {
+        const unsigned short *h1 = reinterpret_cast<const unsigned short *>(a1);
+        const unsigned short *h2 = reinterpret_cast<const unsigned short *>(a2);
+        const unsigned short *hb = reinterpret_cast<const unsigned short *>(b);
+#define WG16(TPW, NA, NB, SH) \
+    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096, s, g, tg, h1, h2, hb, partial)
+#define WG16_TPW(NA, NB, SH)                  \
+    {                                         \
+        if (tpw <= 1) WG16(1, NA, NB, SH);    \
+        else if (tpw == 2) WG16(2, NA, NB, SH); \
+        else if (tpw <= 4) WG16(4, NA, NB, SH); \
+        else WG16(7, NA, NB, SH);             \
+    }
+        if (cfg == 0) {
+            if (sameB) WG16_TPW(7, 2, 1)
+            else WG16_TPW(7, 2, 0)
+        } else {
+            if (sameA) WG16_TPW(1, 8, 2)
+            else WG16_TPW(1, 8, 0)
+        }
+#undef WG16_TPW
+#undef WG16
+        if (check_launch("conv wgrad (bf16 mfma)")) return 1;
+        const long per16 = (long)g.ntaps * C * g.K;
+        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per16, 256)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
+        return check_launch("conv wgrad reduce (bf16 mfma)");
+    }
+    if (cfg == 0 && sameB && g.C2 == 0 && C <= 8 && C % 4 == 0 && g.ntaps * C <= 128 && tg.nslotsA * (C / 4) <= 2 * 256) {
         // narrow-input layer: rows of the GEMM are (tap, channel) pairs
         long ns2 = 512 / tg.nkb;
         if (ns2 < 1) ns2 = 1;
