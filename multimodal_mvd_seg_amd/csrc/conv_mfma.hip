@@ -671,8 +671,7 @@ struct WgTile {
 // NA / NB: float4 per thread of the A halo / B tile (LDS regions are NA*4 KiB and NB*4 KiB).  The NEXT tile's A and B
 // are prefetched into registers while the current tile's MFMAs run.
 // SH: 1 = every tap reads the same B slot (3x3x3 conv: B = dy), 2 = the same A slot (transposed conv), 0 = neither
-// BF: A and B are bf16 in HBM (mixed precision); they are widened to fp32 while staging, the MFMAs stay fp32
-template <int TPW, int NA, int NB, int SH, bool BF>
+template <int TPW, int NA, int NB, int SH>
 __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
                                                        const float *__restrict__ a2, const float *__restrict__ b,
                                                        float *__restrict__ partial) {
@@ -741,13 +740,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
                 ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (aok && idx < na && !(tg.dbg & 1) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi) {
                     const size_t e = ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 4;
-                    if (BF) {
-                        const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(asrc) + e);
-                        ra[u] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
-                                            __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
-                    } else {
-                        ra[u] = *reinterpret_cast<const float4 *>(asrc + e);
-                    }
+                    ra[u] = *reinterpret_cast<const float4 *>(asrc + e);
                 }
             }
         }
@@ -763,13 +756,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
                 rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (bok && idx < nb && !(tg.dbg & 1) && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb) {
                     const size_t e = ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 4;
-                    if (BF) {
-                        const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(b) + e);
-                        rb[u] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u),
-                                            __uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u));
-                    } else {
-                        rb[u] = *reinterpret_cast<const float4 *>(b + e);
-                    }
+                    rb[u] = *reinterpret_cast<const float4 *>(b + e);
                 }
             }
         }
@@ -1142,14 +1129,31 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
     }
 }
 
-// dw[torch layout] = sum_split partial[split][t][c][k]   (fp32 partials, fp64 sum, fixed order)
-__global__ void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial, float *__restrict__ dw, int nsplit) {
+// dw[torch layout] = sum_split partial[split][t][c][k]   (fp32 partials, fp64 sum, fixed order).
+// Block = 64 consecutive elements x 4 split groups: group q sums splits q, q+4, ... (4 loads in flight per thread),
+// the four group sums are combined in a fixed order through LDS.
+__global__ __launch_bounds__(256) void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial,
+                                                        float *__restrict__ dw, int nsplit) {
+    __shared__ double red[4][64];
     const int C = g.C1 + g.C2, K = g.K;
     const long per = (long)g.ntaps * C * K;
-    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= per) return;
-    double s = 0;
-    for (int b = 0; b < nsplit; b++) s += (double)partial[(size_t)b * per + j];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + e;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (j < per) {
+        int b = q;
+        for (; b + 12 < nsplit; b += 16) {
+            s0 += (double)partial[(size_t)b * per + j];
+            s1 += (double)partial[(size_t)(b + 4) * per + j];
+            s2 += (double)partial[(size_t)(b + 8) * per + j];
+            s3 += (double)partial[(size_t)(b + 12) * per + j];
+        }
+        for (; b < nsplit; b += 4) s0 += (double)partial[(size_t)b * per + j];
+    }
+    red[q][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q != 0 || j >= per) return;
+    const double s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     const int k = (int)(j % K);
     const int c = (int)((j / K) % C);
     const int t = g.wt[(int)(j / ((long)K * C))];
@@ -1273,16 +1277,16 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     dim3 grid(tg.nsplit, ncb * tg.nkb);
 #define WG_LAUNCH(TPW, NA, NB, SH)                                                                                   \
     {                                                                                                              \
-        auto kern = bf16_in ? k_wgrad_mfma<TPW, NA, NB, SH, true> : k_wgrad_mfma<TPW, NA, NB, SH, false>;                                                                  \
+        auto kern = k_wgrad_mfma<TPW, NA, NB, SH>;                                                                 \
         const size_t lds = (size_t)(NA + NB) * 4096;                                                               \
-        static bool cfgd[2] = {false, false};                                                                      \
-        if (!cfgd[bf16_in ? 1 : 0]) {                                                                              \
+        static bool cfgd = false;                                                                                  \
+        if (!cfgd) {                                                                                               \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)LDS_LIMIT) != hipSuccess) {                                               \
                 set_error("conv wgrad (mfma): cannot raise the dynamic LDS limit");                                \
                 return 1;                                                                                          \
             }                                                                                                      \
-            cfgd[bf16_in ? 1 : 0] = true;                                                                          \
+            cfgd = true;                                                                                           \
         }                                                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tg, a1, a2, b, partial);                              \
     }
@@ -1315,7 +1319,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
 #undef WG16
         if (check_launch("conv wgrad (bf16 mfma)")) return 1;
         const long per16 = (long)g.ntaps * C * g.K;
-        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per16, 256)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
+        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per16, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
         return check_launch("conv wgrad reduce (bf16 mfma)");
     }
     if (cfg == 0 && sameB && g.C2 == 0 && C <= 8 && C % 4 == 0 && g.ntaps * C <= 128 && tg.nslotsA * (C / 4) <= 2 * 256) {
@@ -1330,7 +1334,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         hipLaunchKernelGGL(kern, dim3(tg.nsplit, tg.nkb), dim3(256), lds2, s, g, tg, a1, b, partial);
         if (check_launch("conv wgrad (mfma, narrow input)")) return 1;
         const long per2 = (long)g.ntaps * C * g.K;
-        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per2, 256)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
+        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per2, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
         return check_launch("conv wgrad reduce (mfma)");
     }
 #define WG_TPW(NA, NB, SH)                     \
@@ -1351,7 +1355,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
 #undef WG_LAUNCH
     if (check_launch("conv wgrad (mfma)")) return 1;
     const long per = (long)g.ntaps * C * g.K;
-    hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per, 256)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
+    hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
     return check_launch("conv wgrad reduce (mfma)");
 }
 

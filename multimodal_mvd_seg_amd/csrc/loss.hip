@@ -177,6 +177,69 @@ __global__ void k_seghead_dw4(const float *__restrict__ x, const float *__restri
     }
 }
 
+// V % 4 == 0 variant: a thread walks QUADS of consecutive voxels, so the planar dlogits come in as one float4 per
+// class (instead of 4 scalar loads) next to the 4 channel rows; no per-voxel division (n, v advance incrementally)
+template <bool XB>
+__global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
+                               int N, long V, int C, int K, long chunk) {
+    extern __shared__ float smf[];  // [R][K*C + K]
+    const int t = threadIdx.x;
+    const int CG = C / 4, R = blockDim.x / CG;
+    const int g = t % CG, r = t / CG;
+    const long total = (long)N * V;
+    const long g0 = (long)blockIdx.x * chunk;
+    long g1 = g0 + chunk;
+    if (g1 > total) g1 = total;
+    const int nv_out = K * C + K;
+    float acc[KMAX][4], accb[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        accb[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[k][j] = 0.f;
+    }
+    if (r < R) {
+        long i = g0 + 4L * r;
+        long n = i / V, v = i - n * V;
+        const long step = 4L * R;
+        for (; i < g1; i += step) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) q[u] = ld4<XB>(x, (size_t)(i + u) * C + g * 4);
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                if (k < K) {
+                    const float4 d = *reinterpret_cast<const float4 *>(dl + ((size_t)n * K + k) * V + v);
+                    acc[k][0] += d.x * q[0].x + d.y * q[1].x + d.z * q[2].x + d.w * q[3].x;
+                    acc[k][1] += d.x * q[0].y + d.y * q[1].y + d.z * q[2].y + d.w * q[3].y;
+                    acc[k][2] += d.x * q[0].z + d.y * q[1].z + d.z * q[2].z + d.w * q[3].z;
+                    acc[k][3] += d.x * q[0].w + d.y * q[1].w + d.z * q[2].w + d.w * q[3].w;
+                    accb[k] += (d.x + d.y) + (d.z + d.w);
+                }
+            v += step;
+            while (v >= V) {
+                v -= V;
+                n++;
+            }
+        }
+        float *o = smf + (size_t)r * nv_out;
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[k * C + g * 4 + j] = acc[k][j];
+                if (g == 0) o[K * C + k] = accb[k];
+            }
+    }
+    __syncthreads();
+    double *po = partial + (size_t)blockIdx.x * nv_out;
+    for (int j = t; j < nv_out; j += blockDim.x) {
+        double s = 0;
+        for (int rr = 0; rr < R; rr++) s += (double)smf[(size_t)rr * nv_out + j];
+        po[j] = s;
+    }
+}
+
 // =============================================================================================== DC + CE
 __device__ inline int label_of(float t, int K) {
     int y = (int)t;  // .long() truncation (robust_ce_loss.py:16)
@@ -567,7 +630,10 @@ static int seghead_bwd_impl(const float *x, bool xb, const float *w, const float
         double *partial = reinterpret_cast<double *>(ws);
         const int CG = C / 4, R = (C % 4 == 0 && CG <= 256) ? 256 / CG : 0;
         const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
-        if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0)
+        if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0 && V % 4 == 0 && (((uintptr_t)dlogits) & 15) == 0)
+            hipLaunchKernelGGL(xb ? k_seghead_dw4v<true> : k_seghead_dw4v<false>, dim3(nblk), dim3((R * CG + 63) / 64 * 64),
+                               smb, s, x, dlogits, partial, N, V, C, K, chunk);
+        else if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0)
             hipLaunchKernelGGL(xb ? k_seghead_dw4<true> : k_seghead_dw4<false>, dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s, x, dlogits, partial, N, V,
                                C, K, chunk);
         else

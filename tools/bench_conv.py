@@ -29,7 +29,11 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     args = ap.parse_args()
+    bf = args.dtype == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    sfx = "_bf16" if bf else ""
     dev = torch.device("cuda:0")
     P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -37,15 +41,17 @@ def main():
     for name in args.layers.split(","):
         C1, C2, K, S, st = LAYERS[name]
         So = S // st
-        x1 = ops.empty_cl3d((N, C1, S, S, S), dev).normal_()
-        x2 = ops.empty_cl3d((N, C2, S, S, S), dev).normal_() if C2 else None
+        if bf and (C1 % 32 or K % 32):
+            continue
+        x1 = ops.empty_cl3d((N, C1, S, S, S), dev, dt).normal_()
+        x2 = ops.empty_cl3d((N, C2, S, S, S), dev, dt).normal_() if C2 else None
         w = torch.randn(K, C1 + C2, 3, 3, 3, device=dev) * 0.03
-        wf, wb = ops.pack_weight(w, False)
+        wf, wb = ops.pack_weight_bf16(w, False) if bf else ops.pack_weight(w, False)
         bias = torch.zeros(K, device=dev)
-        y = ops.empty_cl3d((N, K, So, So, So), dev)
-        dy = ops.empty_cl3d((N, K, So, So, So), dev).normal_()
-        dx1 = ops.empty_cl3d((N, C1, S, S, S), dev)
-        dx2 = ops.empty_cl3d((N, C2, S, S, S), dev) if C2 else None
+        y = ops.empty_cl3d((N, K, So, So, So), dev, dt)
+        dy = ops.empty_cl3d((N, K, So, So, So), dev, dt).normal_()
+        dx1 = ops.empty_cl3d((N, C1, S, S, S), dev, dt)
+        dx2 = ops.empty_cl3d((N, C2, S, S, S), dev, dt) if C2 else None
         dw = torch.empty_like(w)
         db = torch.empty(K, device=dev)
         nb = max(query("mvd_conv3d_wgrad_workspace_bytes", C1 + C2, K, 27, N, So, So, So),
@@ -54,11 +60,11 @@ def main():
         ks, sd = i3((3, 3, 3)), i3((st, st, st))
         flops = 2.0 * 27 * (C1 + C2) * K * N * So ** 3
         fns = {
-            "fwd": lambda: call("mvd_conv3d_fwd", P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, S, S, S, K, ks, sd, P(ws),
+            "fwd": lambda: call("mvd_conv3d_fwd" + sfx, P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, S, S, S, K, ks, sd, P(ws),
                                 ws.numel(), s),
-            "dgrad": lambda: call("mvd_conv3d_dgrad", P(dy), P(wb), P(dx1), C1, P(dx2), C2, N, S, S, S, K, ks, sd, P(ws),
+            "dgrad": lambda: call("mvd_conv3d_dgrad" + sfx, P(dy), P(wb), P(dx1), C1, P(dx2), C2, N, S, S, S, K, ks, sd, P(ws),
                                   ws.numel(), s),
-            "wgrad": lambda: call("mvd_conv3d_wgrad", P(x1), C1, P(x2), C2, P(dy), P(dw), P(db), N, S, S, S, K, ks, sd,
+            "wgrad": lambda: call("mvd_conv3d_wgrad" + sfx, P(x1), C1, P(x2), C2, P(dy), P(dw), P(db), N, S, S, S, K, ks, sd,
                                   P(ws), ws.numel(), s),
         }
         for what in args.what.split(","):
@@ -72,8 +78,10 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
-            print(f"{name:12s} {what:6s} C={C1}+{C2} K={K} S={S} st={st}: {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s",
-                  flush=True)
+            eb = 2 if bf else 4
+            gb = N * (S ** 3 * (C1 + C2) + So ** 3 * K) * eb / 1e9  # algorithmic bytes: every activation once
+            print(f"{name:12s} {what:6s} C={C1}+{C2} K={K} S={S} st={st}: {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s"
+                  f"  {gb / ms * 1e3:7.1f} GB/s (algorithmic)", flush=True)
         del x1, x2, y, dy, dx1, dx2, ws
 
 
