@@ -154,13 +154,18 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--patch", type=int, nargs=3, default=list(PATCH), help="debug only; the metric is quoted at 128^3")
     ap.add_argument("--backend", default="nccl", help="debug only: 'gloo' lets several ranks share one GPU")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4"],
-                    help="cfg2 = the metric's workload (default); cfg3 = + mutual-distillation dual branch (KL on the "
-                         "vessel logits + feature KL); cfg4 = cfg3 + soft-clDice topology term (both fp32 this round)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fp32 = the metric's configuration (default); bf16 = mixed precision of BASELINE cfg 4/5 (bf16 "
-                         "activations on the bf16 MFMA engine, fp32 master weights/statistics/losses/optimizer)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="BASELINE.json configs[1..4]: cfg2 = the metric's workload (default); cfg3 = + mutual-distillation "
+                         "dual branch (KL on the vessel logits + feature KL); cfg4 = cfg3 + soft-clDice topology term, "
+                         "bf16; cfg5 = single branch on the 160x160x128 patch, bf16")
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="auto = what BASELINE.json names for the config (fp32 for cfg2/cfg3, bf16 for cfg4/cfg5); bf16 = "
+                         "bf16 activations on the bf16 MFMA engine, fp32 master weights/statistics/losses/optimizer")
     args = ap.parse_args()
+    if args.precision == "auto":
+        args.precision = "bf16" if args.config in ("cfg4", "cfg5") else "fp32"
+    if args.config == "cfg5" and tuple(args.patch) == PATCH:
+        args.patch = [160, 160, 128]
 
     import torch
     import torch.distributed as dist
@@ -181,7 +186,7 @@ def main():
     from multimodal_mvd_seg_amd import trainer
     patch = tuple(args.patch)
     plans = trainer.make_plans(patch, STRIDES, batch_size=PER_GPU_BATCH * world)
-    if args.config == "cfg2":
+    if args.config in ("cfg2", "cfg5"):
         tr = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, dataset_json(), device=dev)
     else:
         tr = trainer.ContrastiveTrainerMI355(plans, "3d_fullres", 0, dataset_json(), device=dev)
@@ -189,7 +194,7 @@ def main():
     torch.manual_seed(0)
     tr.precision = args.precision
     tr.initialize()
-    if args.config != "cfg2":
+    if args.config in ("cfg3", "cfg4"):
         tr.dummy_batch = tr.make_dummy_batch()
     assert tr.batch_size == PER_GPU_BATCH
     tr.on_train_epoch_start()
@@ -221,7 +226,9 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
                "data": "synthetic",
-               "config": {"workload": ("BASELINE configs[1]" if args.config == "cfg2" else f"BASELINE {args.config} (dual-branch MVD step)") +
+               "config": {"workload": {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2] (dual-branch MVD step)",
+                                       "cfg4": "BASELINE configs[3] (dual-branch MVD step + soft-clDice)",
+                                       "cfg5": "BASELINE configs[4]"}[args.config] +
                                       ": PlainConvUNet 3d_fullres 6 stages 31.2M params, "
                                       f"{IN_CH}x{'x'.join(map(str, patch))} patch, {NUM_CLASSES} classes, "
                                       f"{'fp32' if args.precision == 'fp32' else 'bf16 mixed precision'}, "

@@ -189,6 +189,12 @@ int mvd_kl_fwd(const float *ys, const float *yt, float *out, int N, int C, long 
 int mvd_kl_bwd(const float *ys, const float *yt, const float *gscale_dev, float gscale_host, float *gs, float *gt,
                int N, int C, long V, long sn, long sc, long sv, float T, float eps_s, int pad_zero_channel,
                void *stream);
+/* bf16 feature maps (mixed precision): dense NDHWC rows [N*V][C], C in {4,8,16,32}, no zero-channel padding; fp32
+ * arithmetic, bf16 gradients.  Workspace: mvd_kl_workspace_bytes. */
+int mvd_kl_fwd_bf16(const uint16_t *ys, const uint16_t *yt, float *out, int N, int C, long V, float T, float eps_s,
+                    void *ws, size_t ws_bytes, void *stream);
+int mvd_kl_bwd_bf16(const uint16_t *ys, const uint16_t *yt, const float *gscale_dev, float gscale_host, uint16_t *gs,
+                    uint16_t *gt, int N, int C, long V, float T, float eps_s, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Soft skeleton primitives (K9).  Replace soft_erode / soft_dilate of soft_skeleton.py:6-22 on planar volumes

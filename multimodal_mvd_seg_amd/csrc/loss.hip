@@ -560,6 +560,71 @@ __global__ void k_kl(const float *__restrict__ ys, const float *__restrict__ yt,
     }
 }
 
+// Dense channel-last rows (the NDHWC feature maps of the feature distillation: [N*V rows][C], C in {4,8,16,32}):
+// C/4 adjacent lanes share a voxel, each holds 4 channels from one 16-byte (fp32) / 8-byte (bf16) load -- fully
+// coalesced -- and the softmax max / sums go across those lanes with xor-shuffles (fixed tree: deterministic).
+// XB: inputs (and the gradients written back) are bf16; arithmetic is fp32 either way.
+template <bool BWD, bool XB>
+__global__ void k_kl_rows(const void *__restrict__ ys, const void *__restrict__ yt, double *__restrict__ partial,
+                          void *__restrict__ gs, void *__restrict__ gt, const float *__restrict__ gscale_dev,
+                          float gscale_host, int N, int C, long V, float T, float eps_s) {
+    __shared__ double red[16];
+    const int parts = C >> 2;  // 1, 2, 4 or 8 lanes per voxel
+    const int part = threadIdx.x & (parts - 1);
+    const long rows = (long)N * V;
+    const int rpb = blockDim.x / parts;
+    const float invT = 1.0f / T;
+    const double coef = (double)T * (double)T / ((double)N * (double)C * (double)V);
+    const float g = BWD ? gscale_host * (gscale_dev ? gscale_dev[0] : 1.0f) * (float)coef * invT : 0.f;
+    double acc[1] = {0.0};
+    // every lane runs the same number of iterations (the shuffles need the whole voxel group alive)
+    for (long r0 = (long)blockIdx.x * rpb; r0 < rows; r0 += (long)gridDim.x * rpb) {
+        const long row = r0 + threadIdx.x / parts;
+        const bool ok = row < rows;
+        const size_t e = (size_t)(ok ? row : 0) * C + part * 4;
+        const float4 s4 = ld4<XB>(ys, e), t4 = ld4<XB>(yt, e);
+        float a[4] = {s4.x * invT + eps_s, s4.y * invT + eps_s, s4.z * invT + eps_s, s4.w * invT + eps_s};
+        float b[4] = {t4.x * invT, t4.y * invT, t4.z * invT, t4.w * invT};
+        float ma = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), mb = fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]));
+        for (int o = 1; o < parts; o <<= 1) {
+            ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+            mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+        }
+        float sa = (expf(a[0] - ma) + expf(a[1] - ma)) + (expf(a[2] - ma) + expf(a[3] - ma));
+        float sb = (expf(b[0] - mb) + expf(b[1] - mb)) + (expf(b[2] - mb) + expf(b[3] - mb));
+        for (int o = 1; o < parts; o <<= 1) {
+            sa += __shfl_xor(sa, o, 64);
+            sb += __shfl_xor(sb, o, 64);
+        }
+        const float lsa = logf(sa), lsb = logf(sb);
+        float p[4], d[4], kl = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float lq = a[c] - ma - lsa, lp = b[c] - mb - lsb;
+            p[c] = expf(lp);
+            d[c] = lp - lq;
+            kl += (p[c] > 0.f) ? p[c] * d[c] : 0.f;
+            if (BWD) a[c] = expf(lq) - p[c];
+        }
+        for (int o = 1; o < parts; o <<= 1) kl += __shfl_xor(kl, o, 64);
+        if (BWD) {
+            if (ok && gs) st4<XB>(gs, e, g * a[0], g * a[1], g * a[2], g * a[3]);
+            if (ok && gt)
+                st4<XB>(gt, e, g * p[0] * (d[0] - kl), g * p[1] * (d[1] - kl), g * p[2] * (d[2] - kl), g * p[3] * (d[3] - kl));
+        } else if (ok && part == 0) {
+            acc[0] += (double)kl;
+        }
+    }
+    if (!BWD) {
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) partial[blockIdx.x] = acc[0] * coef;
+    }
+}
+
+static inline bool kl_rows_ok(int C, long V, long sn, long sc, long sv, int pad) {
+    return !pad && (C == 4 || C == 8 || C == 16 || C == 32) && sc == 1 && sv == C && sn == V * (long)C;
+}
+
 }  // namespace mvd
 
 using namespace mvd;
@@ -746,8 +811,12 @@ int mvd_kl_fwd(const float *ys, const float *yt, float *out, int N, int C, long 
     double *partial = reinterpret_cast<double *>(ws);
     KlIdx ix{sn, sc, sv};
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_kl<false>, dim3(bx), dim3(256), 0, s, ys, yt, partial, nullptr, nullptr, nullptr, 1.f, N, C, V,
-                       ix, T, eps_s, pad);
+    if (kl_rows_ok(C, V, sn, sc, sv, pad) && (((uintptr_t)ys | (uintptr_t)yt) & 15) == 0)
+        hipLaunchKernelGGL((k_kl_rows<false, false>), dim3(bx), dim3(256), 0, s, ys, yt, partial, nullptr, nullptr, nullptr,
+                           1.f, N, C, V, T, eps_s);
+    else
+        hipLaunchKernelGGL(k_kl<false>, dim3(bx), dim3(256), 0, s, ys, yt, partial, nullptr, nullptr, nullptr, 1.f, N, C, V,
+                           ix, T, eps_s, pad);
     if (check_launch("kl_fwd")) return 1;
     return reduce_partials(partial, out, (int)bx, 1, s);
 }
@@ -759,8 +828,37 @@ int mvd_kl_bwd(const float *ys, const float *yt, const float *gscale_dev, float 
     MVD_REQUIRE(!pad || C == 1, "kl_bwd: zero-channel padding is the C==1 branch");
     long bx = grid_for((long)N * V, 4096);
     KlIdx ix{sn, sc, sv};
-    hipLaunchKernelGGL(k_kl<true>, dim3(bx), dim3(256), 0, as_stream(stream), ys, yt, nullptr, gs, gt, gscale_dev,
-                       gscale_host, N, C, V, ix, T, eps_s, pad);
+    if (kl_rows_ok(C, V, sn, sc, sv, pad) && (((uintptr_t)ys | (uintptr_t)yt | (uintptr_t)gs | (uintptr_t)gt) & 15) == 0)
+        hipLaunchKernelGGL((k_kl_rows<true, false>), dim3(grid_for((long)N * V * (C / 4), 8192)), dim3(256), 0,
+                           as_stream(stream), ys, yt, nullptr, gs, gt, gscale_dev, gscale_host, N, C, V, T, eps_s);
+    else
+        hipLaunchKernelGGL(k_kl<true>, dim3(bx), dim3(256), 0, as_stream(stream), ys, yt, nullptr, gs, gt, gscale_dev,
+                           gscale_host, N, C, V, ix, T, eps_s, pad);
     return check_launch("kl_bwd");
+}
+
+int mvd_kl_fwd_bf16(const uint16_t *ys, const uint16_t *yt, float *out, int N, int C, long V, float T, float eps_s,
+                    void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(ys && yt && out && ws, "kl_fwd_bf16: null pointer");
+    MVD_REQUIRE(N > 0 && V > 0 && T > 0 && kl_rows_ok(C, V, V * (long)C, 1, C, 0),
+                "kl_fwd_bf16: dense NDHWC rows with C in {4,8,16,32} only");
+    MVD_REQUIRE(ws_bytes >= mvd_kl_workspace_bytes(N, V), "kl_fwd_bf16: workspace too small");
+    long bx = grid_for((long)N * V, 2048);
+    double *partial = reinterpret_cast<double *>(ws);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL((k_kl_rows<false, true>), dim3(bx), dim3(256), 0, s, ys, yt, partial, nullptr, nullptr, nullptr, 1.f,
+                       N, C, V, T, eps_s);
+    if (check_launch("kl_fwd_bf16")) return 1;
+    return reduce_partials(partial, out, (int)bx, 1, s);
+}
+
+int mvd_kl_bwd_bf16(const uint16_t *ys, const uint16_t *yt, const float *gscale_dev, float gscale_host, uint16_t *gs,
+                    uint16_t *gt, int N, int C, long V, float T, float eps_s, void *stream) {
+    MVD_REQUIRE(ys && yt && (gs || gt), "kl_bwd_bf16: null pointer");
+    MVD_REQUIRE(N > 0 && V > 0 && T > 0 && kl_rows_ok(C, V, V * (long)C, 1, C, 0),
+                "kl_bwd_bf16: dense NDHWC rows with C in {4,8,16,32} only");
+    hipLaunchKernelGGL((k_kl_rows<true, true>), dim3(grid_for((long)N * V * (C / 4), 8192)), dim3(256), 0, as_stream(stream),
+                       ys, yt, nullptr, gs, gt, gscale_dev, gscale_host, N, C, V, T, eps_s);
+    return check_launch("kl_bwd_bf16");
 }
 }

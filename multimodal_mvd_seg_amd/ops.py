@@ -476,6 +476,14 @@ class DistillKLFn(Function):
         out = torch.empty((1,), dtype=torch.float32, device=ys.device)
         nb = query("mvd_kl_workspace_bytes", N, V)
         ws = _Workspace.get(nb, ys.device)
+        if _is_bf16(ys) or _is_bf16(yt):
+            # mixed precision: the bf16 NDHWC feature maps go into the kernel as they are (fp32 arithmetic inside)
+            if not (_is_bf16(ys) and _is_bf16(yt) and _is_cl3d(ys) and (sc, sv, sn) == (1, C, V * C)) or pad_zero_channel:
+                raise RuntimeError("kl: bf16 inputs must both be dense NDHWC feature maps")
+            call("mvd_kl_fwd_bf16", _p(ys), _p(yt), _p(out), N, C, V, float(T), float(eps_s), _p(ws), ws.numel(), _stream())
+            ctx.save_for_backward(ys, yt)
+            ctx.cfg = (gs, float(T), float(eps_s), 0)
+            return out.reshape(())
         call("mvd_kl_fwd", _p(ys), _p(yt), _p(out), N, C, V, sn, sc, sv, float(T), float(eps_s), int(pad_zero_channel),
              _p(ws), ws.numel(), _stream())
         ctx.save_for_backward(ys, yt)
@@ -488,6 +496,11 @@ class DistillKLFn(Function):
         ys, yt = ctx.saved_tensors
         (N, C, V, sn, sc, sv), T, eps_s, pad = ctx.cfg
         g = g.contiguous()
+        if _is_bf16(ys):
+            gs = torch.empty_like(ys) if ctx.needs_input_grad[0] else None
+            gt = torch.empty_like(yt) if ctx.needs_input_grad[1] else None
+            call("mvd_kl_bwd_bf16", _p(ys), _p(yt), _p(g), 1.0, _p(gs), _p(gt), N, C, V, T, eps_s, _stream())
+            return gs, gt, None, None, None
         # gradients are written with the inputs' strides into buffers of identical geometry
         def like(t):
             return torch.empty_strided(t.shape, t.stride(), dtype=torch.float32, device=t.device) \

@@ -321,7 +321,6 @@ class ContrastiveTrainerMI355(nnUNetTrainerMI355):
         tgt0 = target[0] if isinstance(target, (list, tuple)) else target
         mutual = losses.kl_loss_compute1(top1[:, v], top2[:, v], self.kl_T)
         if self.feat_kl:
-            f1, f2 = ops.widen(f1), ops.widen(f2)  # bf16 feature maps cross into the fp32 KL kernel
             mutual = mutual + losses.l2_loss(f1, f2, channel_wise=True, T=self.kl_T)
         l = l + self.lambda1 * mutual
         if self.use_topo:

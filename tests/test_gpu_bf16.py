@@ -295,3 +295,27 @@ def test_unet_bf16_step_no_worse_than_torch_autocast():
     tr.on_train_epoch_start()
     res = tr.train_step({"data": batch["data"].to(DEV), "target": [t.to(DEV) for t in batch["target"]]})
     assert np.isfinite(float(res["loss"]))
+
+
+@pytest.mark.parametrize("C,T", [(32, 1.0), (8, 4.0)])
+def test_feature_kl_bf16_rows(C, T):
+    """feature distillation on bf16 NDHWC feature maps: fp32 arithmetic inside, so the loss matches the fp64 oracle
+    on the same rounded inputs at fp32 level and the (bf16) gradients to 1 bf16 ulp."""
+    from multimodal_mvd_seg_amd import losses
+    from oracle import loss_oracle as LO
+    g = torch.Generator().manual_seed(C)
+    sp = (5, 6, 7)
+    a = bf(torch.randn(2, C, *sp, generator=g) * 2)
+    b = bf(torch.randn(2, C, *sp, generator=g) * 2)
+    ar, br = a.double().requires_grad_(), b.double().requires_grad_()
+    ref = LO.l2_loss(ar, br, channel_wise=True, T=T)
+    ref.backward()
+    cl = torch.channels_last_3d
+    ga = a.to(DEV).contiguous(memory_format=cl).requires_grad_()
+    gb = b.to(DEV).contiguous(memory_format=cl).requires_grad_()
+    out = losses.l2_loss(ga, gb, channel_wise=True, T=T)
+    assert abs(float(out) - float(ref)) <= 2e-5 * abs(float(ref)) + 1e-7
+    out.backward()
+    assert ga.grad.dtype == torch.bfloat16 and gb.grad.dtype == torch.bfloat16
+    close_bf16(ga.grad, ar.grad, "d student")
+    close_bf16(gb.grad, br.grad, "d teacher")
