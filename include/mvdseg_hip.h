@@ -34,6 +34,8 @@ const char *mvd_last_error(void);
 int mvd_has_mfma(void);
 /* force the scalar gather kernels (debug / cross-check): 0 = auto (MFMA when shapes allow), 1 = scalar only */
 int mvd_set_conv_engine(int mode);
+/* debug/test hook: minimum number of 128-voxel x 32-channel work items for the Winograd conv kernel (n < 0: default) */
+int mvd_set_wino_min_items(long n);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight packing.  torch Conv3d weight [K][C][T] (T = kd*kh*kw taps, row-major) ->
@@ -60,6 +62,22 @@ int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float
 int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float *dx2, int C2, int N, int D, int H,
                      int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream);
 /* wgrad: dw in TORCH layout [K][C1+C2][T], dbias [K] (may be NULL).  Fixed-order split reduction through `ws`. */
+/* Winograd F(2,3)-along-W variants of the two entries above for 3x3x3 stride-1 convs with C % 32 == 0, K % 32 == 0
+ * (every conv of the network but the input layer and the strided ones): 2/3 of the multiply-adds of the direct
+ * form, fp32 throughout, same results within fp32 round-off (tests: <= 1e-5 relative to fp64).
+ * mvd_pack_weight_wino: torch weight [K][C][3][3][3] -> uf (forward) / ub (input gradient), 36*C*K floats each,
+ * layout [chunk32][(dz,dy)][position 0..3][lane half][out channel][16].  The *_wino conv entries take the direct
+ * packed weights as well and fall back to the direct engines (same results) for shapes the Winograd kernel does
+ * not cover (strides, 1x1x1, fewer than ~1024 tiles, uf/ub == NULL). */
+/* bit 0: the forward would use the Winograd kernel, bit 1: the input gradient would (0: skip packing uf/ub) */
+int mvd_conv_wino_applicable(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3], const int stride[3]);
+int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream);
+int mvd_conv3d_fwd_wino(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
+                        const float *bias, float *y, int N, int D, int H, int W, int K, const int ksize[3],
+                        const int stride[3], void *ws, size_t ws_bytes, void *stream);
+int mvd_conv3d_dgrad_wino(const float *dy, const float *wb, const float *ub, float *dx1, int C1, float *dx2, int C2, int N,
+                          int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                          void *stream);
 size_t mvd_conv3d_wgrad_workspace_bytes(int C, int K, int T, int N, int Do, int Ho, int Wo);
 int mvd_conv3d_wgrad(const float *x1, int C1, const float *x2, int C2, const float *dy, float *dw, float *dbias,
                      int N, int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws,

@@ -19,6 +19,7 @@ SIGNATURES = {
     "mvd_last_error": (ctypes.c_char_p, []),
     "mvd_has_mfma": (c_int, []),
     "mvd_set_conv_engine": (c_int, [c_int]),
+    "mvd_set_wino_min_items": (c_int, [c_long]),
     "mvd_pack_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_conv_fwd_workspace_bytes": (c_size_t, [c_int, c_long, c_int]),
     "mvd_conv3d_fwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
@@ -32,6 +33,12 @@ SIGNATURES = {
     "mvd_convT3d_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
     "mvd_convT3d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mvd_convT3d_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
+    "mvd_conv_wino_applicable": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
+    "mvd_pack_weight_wino": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "mvd_conv3d_fwd_wino": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
+                                    c_size_t, _P]),
+    "mvd_conv3d_dgrad_wino": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
+                                      c_size_t, _P]),
     "mvd_conv3d_wgrad_bf16": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                       c_size_t, _P]),
     "mvd_convT3d_wgrad_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t,

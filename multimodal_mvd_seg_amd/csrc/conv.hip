@@ -6,6 +6,10 @@
 namespace mvd {
 
 static int g_engine_mode = 0;  // 0 auto, 1 scalar only
+// Winograd F(2,3) engine switches (debug): MVD_WINO=0 disables it, MVD_WINO_MIN overrides the minimum number of
+// 128-voxel x 32-channel work items below which the direct engines (which can split the reduction) are used
+static const int g_wino_off = getenv("MVD_WINO") ? (atoi(getenv("MVD_WINO")) == 0) : 0;
+static long g_wino_min_items = getenv("MVD_WINO_MIN") ? atol(getenv("MVD_WINO_MIN")) : 1024;
 
 // =============================================================================================== scalar forward-type
 // one thread per (n, o, k); k fastest so weight reads and output writes are coalesced and A is a wave broadcast
@@ -295,8 +299,17 @@ static void conv_fwd_geom(FwdGeom &g, int N, int D, int H, int W, int C1, int C2
     }
 }
 
+// u (optional): Winograd-domain weights of mvd_pack_weight_wino for this pass (uf for the forward, ub for the input
+// gradient); used for plain 3x3x3 stride-1 problems with enough tiles to fill the chip, the direct engines otherwise
 static int run_fwd(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
-                   float *y2, void *ws, size_t ws_bytes, hipStream_t s) {
+                   float *y2, void *ws, size_t ws_bytes, hipStream_t s, const float *u = nullptr) {
+    if (g_engine_mode == 0 && u && !g_wino_off) {
+        const long tiles = (long)g.N * ((g.Do + 3) / 4) * ((g.Ho + 3) / 4) * ((g.Wo + 7) / 8) * ((g.K1 + g.K2) / 32);
+        if (tiles >= g_wino_min_items) {
+            int r = fwd_wino(g, a1, a2, u, bias, y1, y2, s);
+            if (r >= 0) return r;
+        }
+    }
     if (g_engine_mode == 0) {
         int r = fwd_mfma(g, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
         if (r >= 0) return r;
@@ -348,21 +361,72 @@ int mvd_set_conv_engine(int mode) {
     return 0;
 }
 
+int mvd_set_wino_min_items(long n) {
+    g_wino_min_items = n < 0 ? 1024 : n;
+    return 0;
+}
+
 size_t mvd_conv_fwd_workspace_bytes(int N, long out_voxels, int K) { return fwd_mfma_ws(N, out_voxels, K); }
 
-int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *bias, float *y, int N,
-                   int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
-                   void *stream) {
+static int conv3d_fwd_impl(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
+                           const float *bias, float *y, int N, int D, int H, int W, int K, const int ksize[3],
+                           const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(x1 && wf && y && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_fwd: null pointer / bad channels");
     MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_fwd: bad shape");
     if (check_ks(ksize, stride, "conv3d_fwd")) return 2;
     FwdGeom g;
     conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
-    return run_fwd(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream));
+    return run_fwd(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream), uf);
 }
+
+int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *bias, float *y, int N,
+                   int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                   void *stream) {
+    return conv3d_fwd_impl(x1, C1, x2, C2, wf, nullptr, bias, y, N, D, H, W, K, ksize, stride, ws, ws_bytes, stream);
+}
+
+int mvd_conv3d_fwd_wino(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
+                        const float *bias, float *y, int N, int D, int H, int W, int K, const int ksize[3],
+                        const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    return conv3d_fwd_impl(x1, C1, x2, C2, wf, uf, bias, y, N, D, H, W, K, ksize, stride, ws, ws_bytes, stream);
+}
+
+/* 1 when mvd_conv3d_fwd_wino / mvd_conv3d_dgrad_wino would run the Winograd kernel for this conv (the caller can skip
+ * packing uf/ub otherwise).  Cin/Cout: reduce / produce channel counts of the pass (swap them for the dgrad). */
+int mvd_conv_wino_applicable(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3], const int stride[3]) {
+    if (g_engine_mode != 0 || g_wino_off) return 0;
+    for (int a = 0; a < 3; a++)
+        if (ksize[a] != 3 || stride[a] != 1) return 0;
+    if (C1 % 32 || C2 % 32 || K % 32 || C1 <= 0 || K <= 0) return 0;
+    const long tiles_f = (long)N * ((D + 3) / 4) * ((H + 3) / 4) * ((W + 7) / 8) * (K / 32);
+    const long tiles_b = (long)N * ((D + 3) / 4) * ((H + 3) / 4) * ((W + 7) / 8) * ((C1 + C2) / 32);
+    return (tiles_f >= g_wino_min_items ? 1 : 0) | (tiles_b >= g_wino_min_items ? 2 : 0);
+}
+
+int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream) {
+    MVD_REQUIRE(w && (uf || ub) && K > 0 && C > 0, "pack_weight_wino: bad arguments");
+    MVD_REQUIRE(K % 32 == 0 && C % 32 == 0, "pack_weight_wino: needs C %% 32 == 0 and K %% 32 == 0");
+    return pack_weight_wino(w, uf, ub, K, C, as_stream(stream));
+}
+
+static int conv3d_dgrad_impl(const float *dy, const float *wb, const float *ub, float *dx1, int C1, float *dx2, int C2,
+                             int N, int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws,
+                             size_t ws_bytes, void *stream);
 
 int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float *dx2, int C2, int N, int D, int H, int W,
                      int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    return conv3d_dgrad_impl(dy, wb, nullptr, dx1, C1, dx2, C2, N, D, H, W, K, ksize, stride, ws, ws_bytes, stream);
+}
+
+int mvd_conv3d_dgrad_wino(const float *dy, const float *wb, const float *ub, float *dx1, int C1, float *dx2, int C2, int N,
+                          int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
+                          void *stream) {
+    return conv3d_dgrad_impl(dy, wb, ub, dx1, C1, dx2, C2, N, D, H, W, K, ksize, stride, ws, ws_bytes, stream);
+}
+
+static int conv3d_dgrad_impl(const float *dy, const float *wb, const float *ub, float *dx1, int C1, float *dx2, int C2,
+                             int N, int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws,
+                             size_t ws_bytes, void *stream) {
     MVD_REQUIRE(dy && wb && dx1 && C1 > 0 && C2 >= 0 && (C2 == 0 || dx2), "conv3d_dgrad: null pointer / bad channels");
     MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_dgrad: bad shape");
     if (check_ks(ksize, stride, "conv3d_dgrad")) return 2;
@@ -414,7 +478,7 @@ int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float
                 g.ntaps = nt;
                 g.T = ksize[0] * ksize[1] * ksize[2];
                 if (nt == 0) continue;
-                int r = run_fwd(g, dy, nullptr, wb, nullptr, dx1, dx2, ws, ws_bytes, as_stream(stream));
+                int r = run_fwd(g, dy, nullptr, wb, nullptr, dx1, dx2, ws, ws_bytes, as_stream(stream), ub);
                 if (r) return r;
             }
     return 0;

@@ -71,6 +71,11 @@ size_t wgrad_mfma_ws(const WgradGeom &g);
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
                hipStream_t s, bool bf16_in = false);
 
+// fp32 Winograd F(2,3)-along-W engine for plain 3x3x3 stride-1 problems (conv_wino.hip); u = Winograd-domain weights
+int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,
+             hipStream_t s);
+int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s);
+
 // bf16 forward-type engine (conv_bf16.hip): bf16 activations / packed weights, fp32 accumulate, bf16 output
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
              const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,288 @@
+// fp32 3x3x3 stride-1 convolution (forward and input-gradient) with the Winograd F(2,3) transform along W.
+//
+// For a pair of neighbouring outputs (w = 2q, 2q+1) and one (dz,dy) row of the filter, the three taps g0,g1,g2 along W
+// read the four inputs d0..d3 = x[2q-1 .. 2q+2]:
+//     m0 = (d0 - d2) g0            m1 = (d1 + d2) (g0+g1+g2)/2
+//     m2 = (d2 - d1) (g0-g1+g2)/2  m3 = (d1 - d3) g2
+//     y[2q] = m0 + m1 + m2         y[2q+1] = m1 - m2 - m3
+// i.e. 4 channel-contractions instead of 6: the MFMA work of the gathered-tap GEMM drops by 1/3 (36 "taps" over V/2
+// pairs instead of 27 over V voxels).  The fp32 error is that of the direct form (coefficients are 1 and 1/2;
+// measured 6.9e-7 vs 4.6e-7 relative for a 32-channel layer), inside the 1e-4 parity bar.
+//
+//   * workgroup = 4 waves = a 4 x 4 x 8 voxel tile (64 pairs) x 32 output channels; the GEMM M index of a wave is the
+//     pair (2 d-planes x 4 rows x 4 pairs); the four Winograd positions are split over two wave pairs;
+//   * the halo tile [6 x 6 x 10 slots][32 ch] of a 32-channel chunk is staged once in LDS (whole 128-byte lines, padded
+//     to 36 floats); the input transform is done ON THE FLY on the operands read from it (16 VALU adds per 16 MFMAs),
+//     so the LDS tile is the plain halo and three workgroups fit a CU;
+//   * the transformed weights U = G g (36 x C x K, precomputed by mvd_pack_weight_wino in the MFMA operand order) are
+//     NOT staged: every lane fetches its B fragment (16 consecutive floats) straight from L2, one position ahead of the
+//     MFMAs that use it -- no weight ring, no barrier inside a chunk;
+//   * the output transform runs on the accumulators in the epilogue; bias is added there.
+#include "common.h"
+#include "conv_geom.h"
+
+namespace mvd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WinoTile {
+    int EH, EW, nslots;
+    int magW, magHW;
+    int ntd, nth, ntw, nkb;
+    int nitems;
+    int K;
+    int dbg;  // MVD_WINO_DBG ablation bits: 1 no activation loads, 2 no MFMAs, 4 no weight prefetch loads
+};
+
+// U layout: [cc][g = (oz+1)*3 + (oy+1)][p][e4][h][k][4], reduce channel c = cc*32 + h*16 + e (e = e4*4 + c4): the
+// e4-th 16-byte load of a wave (lanes (h, k)) is two contiguous 512-byte runs
+__host__ __device__ inline size_t uidx(int K, int cc, int g, int p, int h, int k, int e) {
+    return (((((((size_t)cc * 9 + g) * 4 + p) * 4 + (e >> 2)) * 2 + h) * K + k) << 2) + (e & 3);
+}
+
+// w: torch Conv3d weight [K][C][3][3][3].  uf: conv forward (reduce C, produce K); ub: input gradient (reduce K,
+// produce C, taps mirrored: the tap that reads dy at offset o is w[.., 1-o]).
+__global__ void k_pack_wino(const float *__restrict__ w, float *__restrict__ uf, float *__restrict__ ub, int K, int C) {
+    const long total = (long)9 * 4 * C * K;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    // idx enumerates (g, p, c, k) with k fastest
+    const int k = (int)(idx % K);
+    long r = idx / K;
+    const int c = (int)(r % C);
+    r /= C;
+    const int p = (int)(r & 3);
+    const int g = (int)(r >> 2);
+    const int gz = g / 3, gy = g % 3;
+    const float *wp = w + (((size_t)k * C + c) * 27);
+    if (uf) {
+        const float g0 = wp[(gz * 3 + gy) * 3 + 0], g1 = wp[(gz * 3 + gy) * 3 + 1], g2 = wp[(gz * 3 + gy) * 3 + 2];
+        const float u = p == 0 ? g0 : (p == 1 ? (g0 + g1 + g2) * 0.5f : (p == 2 ? (g0 - g1 + g2) * 0.5f : g2));
+        uf[uidx(K, c >> 5, g, p, (c >> 4) & 1, k, c & 15)] = u;
+    }
+    if (ub) {
+        const int mz = 2 - gz, my = 2 - gy;
+        const float g0 = wp[(mz * 3 + my) * 3 + 2], g1 = wp[(mz * 3 + my) * 3 + 1], g2 = wp[(mz * 3 + my) * 3 + 0];
+        const float u = p == 0 ? g0 : (p == 1 ? (g0 + g1 + g2) * 0.5f : (p == 2 ? (g0 - g1 + g2) * 0.5f : g2));
+        ub[uidx(C, k >> 5, g, p, (k >> 4) & 1, c, k & 15)] = u;
+    }
+}
+
+int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s) {
+    const long total = (long)36 * C * K;
+    hipLaunchKernelGGL(k_pack_wino, dim3(cdiv(total, 256)), dim3(256), 0, s, w, uf, ub, K, C);
+    return check_launch("pack_weight_wino");
+}
+
+constexpr int WXS = 36;   // floats per halo slot (32 + 4 pad)
+constexpr int WXR = 12;   // float4 per thread: 360 slots x 8 / 256 threads = 11.25
+constexpr int WXB = 6;    // staging batch (loads in flight per thread)
+
+// Workgroup = 4 waves on one 4 x 4 x 8 voxel tile (64 pairs) x 32 output channels.  Wave w: M half = w & 1 (d-planes
+// 2*(w&1), +1: 32 pairs), position pair ph = w >> 1: waves 0,1 accumulate the Winograd positions p = 0,1 (inputs
+// d0,d1,d2), waves 2,3 the positions p = 2,3 (inputs d1,d2,d3) -- 288 MFMAs each, perfectly balanced, 32 accumulator
+// registers per lane, so three workgroups (12 waves) share a CU.  The output transform needs one accumulator tile of
+// the partner wave (w ^ 2): y[2q] = (m0 + m1) + m2 is finished by waves 0,1, y[2q+1] = (m1 - m2) - m3 by waves 2,3;
+// the tiles cross through the (by then free) halo buffer.
+__global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const WinoTile tg, const float *__restrict__ a1,
+                                                     const float *__restrict__ a2, const float *__restrict__ u,
+                                                     const float *__restrict__ bias, float *__restrict__ y1,
+                                                     float *__restrict__ y2) {
+    extern __shared__ __attribute__((aligned(16))) float Xs[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mh = wave & 1, ph = wave >> 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= tg.nitems) return;  // whole workgroup
+    unsigned r_ = (unsigned)item;
+    const int kb = (int)(r_ % (unsigned)tg.nkb); r_ /= (unsigned)tg.nkb;
+    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+    const int td_ = (int)(r_ % (unsigned)tg.ntd);
+    const int n = (int)(r_ / (unsigned)tg.ntd);
+
+    const int C = g.C1 + g.C2;
+    const int nch = C >> 5;
+    const int EHW = tg.EH * tg.EW;
+    const int nx = tg.nslots * 8;
+    const int od0 = td_ * 4, oh0 = th_ * 4, ow0 = tw_ * 8;
+    const int iz0 = od0 - 1, iy0 = oh0 - 1, ix0 = ow0 - 1;
+
+    // pair i of this wave: d-plane 2*mh + (i >> 4), row (i >> 2) & 3, pair i & 3 of the row; first slot = d0 + ph
+    const int sbase = ((2 * mh + (i >> 4)) * tg.EH + ((i >> 2) & 3)) * tg.EW + 2 * (i & 3) + ph;
+    const float *xlane = Xs + (size_t)sbase * WXS + h * 16;
+    // B fragment of (chunk cc, group gi, position p): four 16-byte quarters of lane (h, k = kb*32 + i)
+    const size_t ustep = (size_t)2 * tg.K * 16;  // floats between consecutive (group, position) blocks
+    const size_t uq = (size_t)2 * tg.K * 4;      // floats between the four quarters of a fragment
+    const float *ulane = u + (((size_t)h * tg.K + kb * 32 + i) << 2) + (size_t)(2 * ph) * ustep;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+
+    for (int cc = 0; cc < nch; cc++) {
+        const int c0 = cc * 32;
+        const float *src;
+        int Cs, cofs;
+        if (c0 < g.C1) {
+            src = a1; Cs = g.C1; cofs = c0;
+        } else {
+            src = a2; Cs = g.C2; cofs = c0 - g.C1;
+        }
+        const float *uc = ulane + (size_t)cc * 36 * ustep;
+        float4 wb[2][4];  // this wave's two positions of the current group; refilled one position ahead
+#pragma unroll
+        for (int e = 0; e < 4; e++) wb[0][e] = *reinterpret_cast<const float4 *>(uc + e * uq);
+        __syncthreads();  // every wave is done with the previous chunk's halo
+        for (int base = 0; base < WXR; base += WXB) {
+            float4 v[WXB];
+#pragma unroll
+            for (int q = 0; q < WXB; q++) {
+                const int idx = (base + q) * 256 + tid;
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < nx && !(tg.dbg & 1)) {
+                    const int slot = idx >> 3;
+                    const int ez = (slot * tg.magHW) >> 16, rem = slot - ez * EHW;
+                    const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
+                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
+                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        v[q] = *reinterpret_cast<const float4 *>(
+                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid & 7) * 4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < WXB; q++) {
+                const int idx = (base + q) * 256 + tid;
+                if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * WXS + (idx & 7) * 4) = v[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int gi = 0; gi < 9; gi++) {
+            const int gz = gi / 3, gy = gi - gz * 3;
+            const float4 *px = reinterpret_cast<const float4 *>(xlane + (size_t)((gz * tg.EH + gy) * tg.EW) * WXS);
+            float4 s0[4], s1[4], s2[4];  // ph = 0: d0, d1, d2;  ph = 1: d1, d2, d3
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                s0[e] = px[e];
+                s1[e] = px[(WXS / 4) + e];
+                s2[e] = px[2 * (WXS / 4) + e];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {
+                // next position's weights: (gi, 1) after (gi, 0), (gi + 1, 0) after (gi, 1); the chunk's last step
+                // re-reads its own block (harmless)
+                const int nxt = pp == 0 ? gi * 4 + 1 : (gi < 8 ? gi * 4 + 4 : gi * 4 + 1);
+                if (!(tg.dbg & 4)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        wb[pp ^ 1][e] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + e * uq);
+                }
+                float4 vv[4];
+                if (ph == 0) {  // wave-uniform: p0 = d0 - d2, p1 = d1 + d2
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        vv[e] = pp == 0 ? make_float4(s0[e].x - s2[e].x, s0[e].y - s2[e].y, s0[e].z - s2[e].z, s0[e].w - s2[e].w)
+                                        : make_float4(s1[e].x + s2[e].x, s1[e].y + s2[e].y, s1[e].z + s2[e].z, s1[e].w + s2[e].w);
+                } else {        // p2 = d2 - d1, p3 = d1 - d3
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        vv[e] = pp == 0 ? make_float4(s1[e].x - s0[e].x, s1[e].y - s0[e].y, s1[e].z - s0[e].z, s1[e].w - s0[e].w)
+                                        : make_float4(s0[e].x - s2[e].x, s0[e].y - s2[e].y, s0[e].z - s2[e].z, s0[e].w - s2[e].w);
+                }
+                if (!(tg.dbg & 2)) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float4 bq = wb[pp][e];
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].x, bq.x, acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].y, bq.y, acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].z, bq.z, acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].w, bq.w, acc[pp], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // output transform: waves 0,1 hold (m0, m1) and finish y[2q] = (m0 + m1) + m2; waves 2,3 hold (m2, m3) and finish
+    // y[2q+1] = (m1 - m2) - m3.  Each wave hands one tile to its partner through the halo buffer.
+    __syncthreads();  // all MFMA operand reads of the halo are done
+    {
+        float *xo = Xs + (size_t)wave * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) xo[r * 64] = ph == 0 ? acc[1][r] : acc[0][r];  // m1 or m2
+    }
+    __syncthreads();
+    const float *xi = Xs + (size_t)(wave ^ 2) * 1024 + lane;
+    const int k = kb * 32 + i;
+    const float bv = bias ? bias[k] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int pi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int od = od0 + 2 * mh + (pi >> 4), oh = oh0 + ((pi >> 2) & 3), ow = ow0 + 2 * (pi & 3) + ph;
+        const float other = xi[r * 64];
+        const float val = ph == 0 ? (acc[0][r] + acc[1][r]) + other + bv : (other - acc[0][r]) - acc[1][r] + bv;
+        if (od < g.Do && oh < g.Ho && ow < g.Wo) {
+            const size_t ov = (((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + ow;
+            if (k < g.K1)
+                y1[ov * g.K1 + k] = val;
+            else
+                y2[ov * g.K2 + (k - g.K1)] = val;
+        }
+    }
+}
+
+// returns -1 when the problem is not a plain 3x3x3 stride-1 gather with 32-multiple channels (caller falls back)
+int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,
+             hipStream_t s) {
+    const int C = g.C1 + g.C2, K = g.K1 + g.K2;
+    if (!u || g.ntaps != 27 || g.T != 27) return -1;
+    if (C % 32 || g.C1 % 32 || g.C2 % 32 || K % 32 || g.K1 % 32 || g.K2 % 32) return -1;
+    for (int a = 0; a < 3; a++)
+        if (g.sa[a] != 1 || g.so[a] != 1 || g.oo[a] != 0) return -1;
+    if (g.Dy != g.Do || g.Hy != g.Ho || g.Wy != g.Wo) return -1;
+    if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)u) & 15) return -1;
+    // the 27 taps must be the full 3x3x3 stencil, either in filter order (forward) or mirrored (input gradient); the
+    // caller passes the matching U (uf / ub of mvd_pack_weight_wino)
+    bool plain = true, mirrored = true;
+    for (int t = 0; t < 27; t++) {
+        const int oz = g.off[t][0], oy = g.off[t][1], ox = g.off[t][2];
+        if (oz < -1 || oz > 1 || oy < -1 || oy > 1 || ox < -1 || ox > 1) return -1;
+        const int pos = ((oz + 1) * 3 + (oy + 1)) * 3 + (ox + 1);
+        if (g.wt[t] != pos) plain = false;
+        if (g.wt[t] != 26 - pos) mirrored = false;
+    }
+    if (!plain && !mirrored) return -1;
+    WinoTile tg;
+    memset(&tg, 0, sizeof(tg));
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("MVD_WINO_DBG") ? atoi(getenv("MVD_WINO_DBG")) : 0;
+    tg.dbg = dbg;
+    tg.EH = 6; tg.EW = 10; tg.nslots = 360;
+    auto magic = [](int d, int nmax) -> int {
+        int m = (1 << 16) / d + 1;
+        for (int n = 0; n < nmax; n++)
+            if (((n * m) >> 16) != n / d) return -1;
+        return m;
+    };
+    tg.magHW = magic(tg.EH * tg.EW, WXR * 32);
+    tg.magW = magic(tg.EW, tg.EH * tg.EW);
+    if (tg.magHW < 0 || tg.magW < 0) return -1;
+    tg.ntd = (g.Do + 3) / 4;
+    tg.nth = (g.Ho + 3) / 4;
+    tg.ntw = (g.Wo + 7) / 8;
+    tg.nkb = K / 32;
+    tg.K = K;
+    const long nitems = (long)g.N * tg.ntd * tg.nth * tg.ntw * tg.nkb;
+    if (nitems > (1L << 30)) return -1;
+    tg.nitems = (int)nitems;
+    const size_t lds = (size_t)tg.nslots * WXS * sizeof(float);
+    const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_fwd_wino, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, u, bias, y1, y2);
+    return check_launch("conv fwd (winograd)");
+}
+
+}  // namespace mvd

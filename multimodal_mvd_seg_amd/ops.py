@@ -155,17 +155,30 @@ class Conv3dFn(Function):
         od = [_out_dim(i, k, s) for i, k, s in zip((D, H, W), ks, stride)]
         y = empty_cl3d((N, K, *od), x1.device, x1.dtype)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, od[0] * od[1] * od[2], K), x1.device)
-        call("mvd_conv3d_fwd_bf16" if bf else "mvd_conv3d_fwd", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H,
-             W, K, i3(ks), i3(stride), _p(ws), ws.numel(), _stream())
+        ub = None
+        if bf:
+            call("mvd_conv3d_fwd_bf16", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
+                 _p(ws), ws.numel(), _stream())
+        else:
+            # fp32 3x3x3 stride-1 layers with enough tiles run the Winograd F(2,3) kernel (2/3 of the MFMA work)
+            wino = query("mvd_conv_wino_applicable", N, D, H, W, C1, C2, K, i3(ks), i3(stride)) if len(ks) == 3 else 0
+            uf = None
+            if wino:
+                w = weight.detach().contiguous()
+                uf = torch.empty((36 * C * K,), dtype=torch.float32, device=w.device) if wino & 1 else None
+                ub = torch.empty((36 * C * K,), dtype=torch.float32, device=w.device) if wino & 2 else None
+                call("mvd_pack_weight_wino", _p(w), _p(uf), _p(ub), K, C, _stream())
+            call("mvd_conv3d_fwd_wino", _p(x1), C1, _p(x2), C2, _p(wf), _p(uf), _p(bias), _p(y), N, D, H, W, K, i3(ks),
+                 i3(stride), _p(ws), ws.numel(), _stream())
         ctx.bf = bf
-        ctx.save_for_backward(x1, x2, wb)
+        ctx.save_for_backward(x1, x2, wb, ub)
         ctx.geom = (N, C1, C2, D, H, W, K, ks, tuple(stride), tuple(od), bias is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x1, x2, wb = ctx.saved_tensors
+        x1, x2, wb, ub = ctx.saved_tensors
         N, C1, C2, D, H, W, K, ks, stride, od, has_bias = ctx.geom
         dy = to_ndhwc(dy)
         dev = dy.device
@@ -176,8 +189,12 @@ class Conv3dFn(Function):
             dx1 = empty_cl3d((N, C1, D, H, W), dev, dy.dtype)
             dx2 = empty_cl3d((N, C2, D, H, W), dev, dy.dtype) if x2 is not None else None
             ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C1 + C2), dev)
-            call("mvd_conv3d_dgrad" + sfx, _p(dy), _p(wb), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks), i3(stride),
-                 _p(ws), ws.numel(), _stream())
+            if ctx.bf:
+                call("mvd_conv3d_dgrad_bf16", _p(dy), _p(wb), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks), i3(stride),
+                     _p(ws), ws.numel(), _stream())
+            else:
+                call("mvd_conv3d_dgrad_wino", _p(dy), _p(wb), _p(ub), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks),
+                     i3(stride), _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[2]:
             T = ks[0] * ks[1] * ks[2]
             dw = torch.empty((K, C1 + C2, *ks), dtype=torch.float32, device=dev)

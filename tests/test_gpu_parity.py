@@ -122,6 +122,47 @@ def test_conv3d_engine_shapes_vs_torch_fp64(C1, C2, K, sp, stride, N):
     close(gb.grad, br.grad, 1e-4, 1e-5, "db")
 
 
+@pytest.mark.parametrize("C1,C2,K,sp,N", [
+    (32, 0, 32, (8, 8, 16), 1),          # whole tiles
+    (32, 0, 32, (9, 7, 13), 2),          # ragged in every axis, odd W (a pair straddles the border)
+    (32, 32, 64, (6, 10, 11), 1),        # two input pointers, two k-blocks
+    (64, 0, 32, (5, 4, 8), 2),           # two chunks
+    (96, 0, 96, (4, 4, 8), 1),           # three chunks, three k-blocks
+])
+def test_conv3d_winograd_engine_vs_torch_fp64(C1, C2, K, sp, N):
+    """fwd and dgrad through the Winograd F(2,3) kernel (forced on for small problems) against fp64; also equality
+    with the direct MFMA engine to fp32 round-off.  dgrad of the two-pointer case writes dx1/dx2 (split outputs)."""
+    from multimodal_mvd_seg_amd import ops
+    from multimodal_mvd_seg_amd._lib import call, query, i3
+    g = torch.Generator().manual_seed(C1 + K + sp[2])
+    x1 = torch.randn(N, C1, *sp, generator=g)
+    x2 = torch.randn(N, C2, *sp, generator=g) if C2 else None
+    w = torch.randn(K, C1 + C2, 3, 3, 3, generator=g) * (1.0 / np.sqrt(27 * (C1 + C2)))
+    b = torch.randn(K, generator=g) * 0.1
+    xs = [t.double().requires_grad_() for t in ([x1, x2] if C2 else [x1])]
+    ref = F.conv3d(torch.cat(xs, 1), w.double(), b.double(), 1, 1)
+    gy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(gy)
+    outs = {}
+    try:
+        for mode, min_items in (("wino", 1), ("direct", 1 << 40)):
+            call("mvd_set_wino_min_items", min_items)
+            assert bool(query("mvd_conv_wino_applicable", N, *sp, C1, C2, K, i3((3, 3, 3)), i3((1, 1, 1)))) == (mode == "wino")
+            g1, g2 = G(x1, True), (G(x2, True) if C2 else None)
+            y = ops.Conv3dFn.apply(g1, g2, G(w, True), G(b, True), (1, 1, 1))
+            y.backward(G(gy.float()))
+            outs[mode] = (y.detach(), g1.grad, g2.grad if C2 else None)
+    finally:
+        call("mvd_set_wino_min_items", -1)
+    y, d1, d2 = outs["wino"]
+    close(y, ref.detach(), 1e-5, 1e-5, "y")
+    close(d1, xs[0].grad, 1e-5, 1e-5, "dx1")
+    if C2:
+        close(d2, xs[1].grad, 1e-5, 1e-5, "dx2")
+    close(y, outs["direct"][0].cpu(), 1e-5, 1e-5, "y vs direct engine")
+    close(d1, outs["direct"][1].cpu(), 1e-5, 1e-5, "dx1 vs direct engine")
+
+
 @pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.startswith("convT3d_")))
 def test_convT3d(name):
     from multimodal_mvd_seg_amd import ops

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--wino", type=int, default=1, help="fp32: 1 = Winograd entries (default, what ops.py calls), 0 = direct")
     args = ap.parse_args()
     bf = args.dtype == "bf16"
     dt = torch.bfloat16 if bf else torch.float32
@@ -59,11 +60,20 @@ def main():
         ws = torch.empty(max(nb, 1024), dtype=torch.uint8, device=dev)
         ks, sd = i3((3, 3, 3)), i3((st, st, st))
         flops = 2.0 * 27 * (C1 + C2) * K * N * So ** 3
+        uf = ub = None
+        if not bf and args.wino and query("mvd_conv_wino_applicable", N, S, S, S, C1, C2, K, i3((3, 3, 3)), i3((st, st, st))):
+            uf = torch.empty(36 * (C1 + C2) * K, device=dev)
+            ub = torch.empty(36 * (C1 + C2) * K, device=dev)
+            call("mvd_pack_weight_wino", P(w), P(uf), P(ub), K, C1 + C2, s)
         fns = {
-            "fwd": lambda: call("mvd_conv3d_fwd" + sfx, P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, S, S, S, K, ks, sd, P(ws),
-                                ws.numel(), s),
-            "dgrad": lambda: call("mvd_conv3d_dgrad" + sfx, P(dy), P(wb), P(dx1), C1, P(dx2), C2, N, S, S, S, K, ks, sd, P(ws),
-                                  ws.numel(), s),
+            "fwd": (lambda: call("mvd_conv3d_fwd_wino", P(x1), C1, P(x2), C2, P(wf), P(uf), P(bias), P(y), N, S, S, S, K, ks,
+                                 sd, P(ws), ws.numel(), s)) if not bf else
+                   (lambda: call("mvd_conv3d_fwd_bf16", P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, S, S, S, K, ks, sd,
+                                 P(ws), ws.numel(), s)),
+            "dgrad": (lambda: call("mvd_conv3d_dgrad_wino", P(dy), P(wb), P(ub), P(dx1), C1, P(dx2), C2, N, S, S, S, K, ks,
+                                   sd, P(ws), ws.numel(), s)) if not bf else
+                     (lambda: call("mvd_conv3d_dgrad_bf16", P(dy), P(wb), P(dx1), C1, P(dx2), C2, N, S, S, S, K, ks, sd,
+                                   P(ws), ws.numel(), s)),
             "wgrad": lambda: call("mvd_conv3d_wgrad" + sfx, P(x1), C1, P(x2), C2, P(dy), P(dw), P(db), N, S, S, S, K, ks, sd,
                                   P(ws), ws.numel(), s),
         }
