@@ -60,7 +60,10 @@ def measured_traffic():
 def dominant_kernel_roofline(torch, dev):
     """Times the dominant kernel of the step in isolation, live, with HIP events: the 3x3x3 conv forward-type
     implicit GEMM on the most expensive layer (decoder stage 5 conv 0: 64 -> 32 channels at 128^3, two input
-    pointers = the eliminated torch.cat), batch 2.  ALGORITHMIC flops = 2*27*C_in*C_out*N_out."""
+    pointers = the eliminated torch.cat), batch 2, through the same entry point ops.Conv3dFn calls.
+    ALGORITHMIC flops = 2*27*C_in*C_out*N_out: the direct-convolution count.  The kernel is the Winograd
+    F(2,3)-along-W engine, which EXECUTES 2/3 of them on the MFMA pipe (36 instead of 54 multiply-adds per output
+    pair and filter row); `executed_tflops` / `mfma_frac_executed` state that separately."""
     from multimodal_mvd_seg_amd import ops
     from multimodal_mvd_seg_amd._lib import call, i3
     import ctypes
@@ -74,16 +77,26 @@ def dominant_kernel_roofline(torch, dev):
     y = ops.empty_cl3d((N, K, D, H, W), dev)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    from multimodal_mvd_seg_amd._lib import query
+    wino = query("mvd_conv_wino_applicable", N, D, H, W, C1, C2, K, i3((3, 3, 3)), i3((1, 1, 1))) & 1
+    uf = None
+    if wino:
+        uf = torch.empty(36 * (C1 + C2) * K, device=dev)
+        call("mvd_pack_weight_wino", P(w), P(uf), None, K, C1 + C2, s)
 
     def conv():
-        call("mvd_conv3d_fwd", P(x1), C1, P(x2), C2, P(wf), P(bias), P(y), N, D, H, W, K, i3((3, 3, 3)), i3((1, 1, 1)),
-             None, 0, s)
+        call("mvd_conv3d_fwd_wino", P(x1), C1, P(x2), C2, P(wf), P(uf) if wino else None, P(bias), P(y), N, D, H, W, K,
+             i3((3, 3, 3)), i3((1, 1, 1)), None, 0, s)
     ms = time_kernel(conv, 3, torch)
     flops = 2.0 * 27 * (C1 + C2) * K * N * D * H * W
     conv_tf = flops / (ms * 1e-3) / 1e12
+    exec_tf = conv_tf * (2.0 / 3.0 if wino else 1.0)
     alg_bytes = ((C1 + C2) + K) * N * D * H * W * 4.0
-    roof = {"kernel": "conv3d_fwd 64->32 @128^3 (fwd-type implicit GEMM)", "bound": "mfma", "achieved": round(conv_tf, 2),
+    roof = {"kernel": "conv3d_fwd 64->32 @128^3 (fwd-type implicit GEMM, " +
+                      ("Winograd F(2,3) along W: k_fwd_wino)" if wino else "direct: k_fwd32)"),
+            "bound": "mfma", "achieved": round(conv_tf, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "executed_tflops": round(exec_tf, 2), "mfma_frac_executed": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": measured_traffic(), "ms_per_launch": round(ms, 3),
             "hbm_view": {"algorithmic_GB": round(alg_bytes / 1e9, 3),
                          "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),

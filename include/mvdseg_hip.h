@@ -68,7 +68,7 @@ int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float
  * mvd_pack_weight_wino: torch weight [K][C][3][3][3] -> uf (forward) / ub (input gradient), 36*C*K floats each,
  * layout [chunk32][(dz,dy)][position 0..3][lane half][out channel][16].  The *_wino conv entries take the direct
  * packed weights as well and fall back to the direct engines (same results) for shapes the Winograd kernel does
- * not cover (strides, 1x1x1, fewer than ~1024 tiles, uf/ub == NULL). */
+ * not cover (strides, 1x1x1, fewer than 256 work items, uf/ub == NULL). */
 /* bit 0: the forward would use the Winograd kernel, bit 1: the input gradient would (0: skip packing uf/ub) */
 int mvd_conv_wino_applicable(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3], const int stride[3]);
 int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream);

@@ -9,7 +9,7 @@ static int g_engine_mode = 0;  // 0 auto, 1 scalar only
 // Winograd F(2,3) engine switches (debug): MVD_WINO=0 disables it, MVD_WINO_MIN overrides the minimum number of
 // 128-voxel x 32-channel work items below which the direct engines (which can split the reduction) are used
 static const int g_wino_off = getenv("MVD_WINO") ? (atoi(getenv("MVD_WINO")) == 0) : 0;
-static long g_wino_min_items = getenv("MVD_WINO_MIN") ? atol(getenv("MVD_WINO_MIN")) : 1024;
+static long g_wino_min_items = getenv("MVD_WINO_MIN") ? atol(getenv("MVD_WINO_MIN")) : 256;
 
 // =============================================================================================== scalar forward-type
 // one thread per (n, o, k); k fastest so weight reads and output writes are coalesced and A is a wave broadcast
@@ -362,7 +362,7 @@ int mvd_set_conv_engine(int mode) {
 }
 
 int mvd_set_wino_min_items(long n) {
-    g_wino_min_items = n < 0 ? 1024 : n;
+    g_wino_min_items = n < 0 ? 256 : n;
     return 0;
 }
 

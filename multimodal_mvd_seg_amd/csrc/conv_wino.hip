@@ -138,11 +138,15 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
 #pragma unroll
         for (int e = 0; e < 4; e++) wb[0][e] = *reinterpret_cast<const float4 *>(uc + e * uq);
         __syncthreads();  // every wave is done with the previous chunk's halo
+        // the slot -> voxel index math is recomputed per chunk on purpose: hoisted out of the chunk loop it would sit
+        // in ~30 registers across the MFMA loop (and spill to scratch = real HBM writes)
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
         for (int base = 0; base < WXR; base += WXB) {
             float4 v[WXB];
 #pragma unroll
             for (int q = 0; q < WXB; q++) {
-                const int idx = (base + q) * 256 + tid;
+                const int idx = (base + q) * 256 + tid_;
                 v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (idx < nx && !(tg.dbg & 1)) {
                     const int slot = idx >> 3;
@@ -151,12 +155,12 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
                     const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
                     if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
                         v[q] = *reinterpret_cast<const float4 *>(
-                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid & 7) * 4);
+                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid_ & 7) * 4);
                 }
             }
 #pragma unroll
             for (int q = 0; q < WXB; q++) {
-                const int idx = (base + q) * 256 + tid;
+                const int idx = (base + q) * 256 + tid_;
                 if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * WXS + (idx & 7) * 4) = v[q];
             }
         }
