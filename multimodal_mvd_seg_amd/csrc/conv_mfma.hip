@@ -845,6 +845,253 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ Winograd wgrad
+// Weight gradient of a 3x3x3 stride-1 conv with the TRANSPOSED F(2,3) algorithm along W.  For an output pair
+// (w = 2q, 2q+1), e = (dy[2q], dy[2q+1]) and the inputs d0..d3 = x[2q-1 .. 2q+2] of one (dz,dy) filter row:
+//     V = B^T d = (d0-d2, d1+d2, d2-d1, d1-d3)        E = A e = (e0, e0+e1, e0-e1, -e1)
+//     M_p[c][k] += V_p[c] * E_p[k]      (p = 0..3: four rank-1 updates per pair instead of six per two voxels)
+//     dW row = G^T M = (M0 + (M1+M2)/2, (M1-M2)/2, (M1+M2)/2 + M3)     (applied by k_wgrad_reduce_wino)
+// The GEMM k dimension is the PAIR index (64 pairs per 2x8x8 tile); wave w owns position p = w for all nine (dz,dy)
+// rows (9 accumulator tiles), so its B operand E_p is shared by its nine MFMAs of a k-step and every A operand costs
+// two LDS reads and one FMA.  Staging, split-K, prefetch and the fp32-partials / fp64 fixed-order reduce are those of
+// k_wgrad_mfma; 36 partial tiles per (c-block, k-block) instead of 27.
+template <int NA, int NB, int NQ>
+__global__ __launch_bounds__(256, 1) void k_wgrad_wino(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+                                                       const float *__restrict__ a2, const float *__restrict__ b,
+                                                       float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;
+    float *Bs = lds + (size_t)NA * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y / tg.nkb, kb = blockIdx.y % tg.nkb;
+    const int split = blockIdx.x;
+    const int C = g.C1 + g.C2, K = g.K;
+
+    // position p = wave: V_p = x[ja] + sg * x[jb], E_p = ea * e0 + eb * e1
+    const int ja = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int jb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+    const float ea = wave == 3 ? 0.f : 1.f;
+    const float eb = wave == 0 ? 0.f : (wave == 1 ? 1.f : -1.f);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    const int c0 = cb * 32;
+    const float *asrc;
+    int Cs, cofs;
+    if (c0 < g.C1) {
+        asrc = a1; Cs = g.C1; cofs = c0;
+    } else {
+        asrc = a2; Cs = g.C2; cofs = c0 - g.C1;
+    }
+    const int k0 = kb * 32;
+    const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
+    const int na = tg.nslotsA * 8, nb = tg.nslotsB * 8;
+    const int part = tid & 7;
+
+    // The slot -> (z,y,x) decode of the staging pass does not depend on the tile: it is done once, here.  Per slot a
+    // thread keeps the element offset relative to the tile origin and the packed halo coordinates (for border tiles).
+    int rela[NA], cza[NA], relb[NB], czb[NB];
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx >> 3;
+        const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
+        const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
+        rela[u] = ((ez * g.Hi + ey) * g.Wi + ex) * Cs + cofs + part * 4;
+        cza[u] = idx < na ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx >> 3;
+        const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
+        const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
+        relb[u] = ((ez * g.Hb + ey) * g.Wb + ex) * K + k0 + part * 4;
+        czb[u] = idx < nb ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+    const int EAd = tg.nslotsA / EAhw, EBd = tg.nslotsB / EBhw;
+
+    float4 ra[NA], rb[NB];
+    auto load_tile = [&](int tile) {
+        unsigned r_ = (unsigned)tile;
+        const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+        const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+        const int td_ = (int)(r_ % (unsigned)tg.ntd);
+        const int n = (int)(r_ / (unsigned)tg.ntd);
+        const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
+        {
+            const int z0 = od0 + tg.minA[0], y0 = oh0 + tg.minA[1], x0 = ow0 + tg.minA[2];
+            // tile origin (may be "before" the tensor for border tiles: only dereferenced through valid slots)
+            const float *base = asrc + ((((long)n * g.Di + z0) * g.Hi + y0) * g.Wi + x0) * (long)Cs;
+            const bool interior = z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + EAd <= g.Di && y0 + tg.EAh <= g.Hi &&
+                                  x0 + tg.EAw <= g.Wi;  // block-uniform
+            if (interior) {
+#pragma unroll
+                for (int u = 0; u < NA; u++) {
+                    ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cza[u] >= 0) ra[u] = *reinterpret_cast<const float4 *>(base + rela[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NA; u++) {
+                    const int id = z0 + (cza[u] >> 16), ih = y0 + ((cza[u] >> 8) & 255), iw = x0 + (cza[u] & 255);
+                    ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cza[u] >= 0 && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        ra[u] = *reinterpret_cast<const float4 *>(base + rela[u]);
+                }
+            }
+        }
+        {
+            const float *base = b + ((((long)n * g.Db + od0) * g.Hb + oh0) * g.Wb + ow0) * (long)K;
+            const bool interior = od0 + EBd <= g.Db && oh0 + tg.EBh <= g.Hb && ow0 + tg.EBw <= g.Wb;
+            if (interior) {
+#pragma unroll
+                for (int u = 0; u < NB; u++) {
+                    rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (czb[u] >= 0) rb[u] = *reinterpret_cast<const float4 *>(base + relb[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NB; u++) {
+                    const int id = od0 + (czb[u] >> 16), ih = oh0 + ((czb[u] >> 8) & 255), iw = ow0 + (czb[u] & 255);
+                    rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (czb[u] >= 0 && id < g.Db && ih < g.Hb && iw < g.Wb)
+                        rb[u] = *reinterpret_cast<const float4 *>(base + relb[u]);
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 256 + tid) * 4) = ra[u];
+#pragma unroll
+        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 256 + tid) * 4) = rb[u];
+    };
+    // ---- k loop.  A k-step is TWO pairs: lane half h takes the d-plane h of the (2 x TH x TW) tile, so a step is a
+    // (row hy, pair column q) position; steps walk q fastest.  The transformed input V_p of halo row r = hy + gy is the
+    // SAME value for the three filter rows gy that touch it, so a wave keeps a sliding window of V in registers --
+    // 3 (gz) x NQ (pair columns) x a ring of 4 rows (row r lives in slot r & 3; the row loop is unrolled by four so all
+    // register indices are static and nothing is ever moved).  Per step: 9 MFMAs, ONE new row piece (3 x 2
+    // ds_read_b32) + (e0, e1), fetched a step ahead under the MFMAs.  Lessons measured with
+    // tools/probes/mfma_probe.hip and earlier versions of this loop: (1) a single wave per SIMD cannot issue 20
+    // four-byte LDS reads per nine MFMAs; (2) overwriting a VGPR that an MFMA issued just before reads as A/B stalls
+    // the writer for the rest of that MFMA (111 vs 137 TFLOP/s) -- here a slot is rewritten >= NQ steps after its
+    // last reader; (3) MFMAs inside divergent-looking branches make hipcc copy accumulator tiles: the loop body is
+    // branch-free.
+    const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
+    const int rowB = tg.EAw * 128;                    // bytes between halo rows
+    const int plB = tg.EAh * tg.EAw * 128;            // bytes between halo planes
+    const int abase = h * plB + i * 4;                // this lane half's d-plane, lane column
+    const int bbase = (h * tg.EBh * tg.EBw) * 128 + i * 4;
+    auto a_addr = [&](int gz, int r, int q) { return abase + gz * plB + r * rowB + q * 256; };
+    float V[3][NQ][4];
+    float e0, e1;
+
+    int tile = split;
+    if (tile < tg.ntiles) load_tile(tile);
+    while (tile < tg.ntiles) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        const int next = tile + tg.nsplit;
+        if (next < tg.ntiles) load_tile(next);
+        // rows 0..2 of every pair column
+#pragma unroll
+        for (int gz = 0; gz < 3; gz++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    const int ad = a_addr(gz, r, q);
+                    V[gz][q][r] = fmaf(sg, *reinterpret_cast<const float *>(Ab + ad + jb * 128),
+                                       *reinterpret_cast<const float *>(Ab + ad + ja * 128));
+                }
+        e0 = *reinterpret_cast<const float *>(Bb + bbase);
+        e1 = *reinterpret_cast<const float *>(Bb + bbase + 128);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int hy0 = 0; hy0 < tg.TH; hy0 += 4) {  // TH is 4 or 8
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const int hy = hy0 + u;
+                    const float bv = fmaf(eb, e1, ea * e0);
+                    // next step: (hy, q + 1) or (hy + 1, 0); the very last one re-reads an in-range row (unused)
+                    const int nh = q + 1 < NQ ? hy : (hy + 1 < tg.TH ? hy + 1 : hy);
+                    const int be = bbase + (nh * tg.EBw + 2 * (q + 1 < NQ ? q + 1 : 0)) * 128;
+                    const int rn = hy + 3 < tg.TH + 2 ? hy + 3 : tg.TH + 1;  // new row of this column (clamped: unused)
+                    float xa[3], xb[3];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[j / 3][q][(u + j % 3) & 3], bv, acc[j], 0, 0, 0);
+                        if (j == 0) {
+                            e0 = *reinterpret_cast<const float *>(Bb + be);
+                            e1 = *reinterpret_cast<const float *>(Bb + be + 128);
+                        } else if (j <= 3) {
+                            const int ad = a_addr(j - 1, rn, q);
+                            xa[j - 1] = *reinterpret_cast<const float *>(Ab + ad + ja * 128);
+                            xb[j - 1] = *reinterpret_cast<const float *>(Ab + ad + jb * 128);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int gz = 0; gz < 3; gz++) V[gz][q][(u + 3) & 3] = fmaf(sg, xb[gz], xa[gz]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        tile = next;
+    }
+    // partial[split][g][p][c][k]; D layout: col = lane&31 -> k, row -> c
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        float *po = partial + (((size_t)split * 9 + j) * 4 + wave) * C * K;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
+        }
+    }
+}
+
+// dw[k][c][gz][gy][0..2] = G^T (sum_split M[split][g][0..3][c][k])   (fp64 sums in a fixed order)
+__global__ __launch_bounds__(256) void k_wgrad_reduce_wino(const float *__restrict__ partial, float *__restrict__ dw,
+                                                           int C, int K, int nsplit) {
+    __shared__ double red[4][64];
+    const long per = (long)36 * C * K;   // one split
+    const long nout = (long)9 * C * K;   // (g, c, k) triples; each owns 4 positions
+    const int e = threadIdx.x & 63, p = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + e;
+    double s0 = 0, s1 = 0;
+    if (j < nout) {
+        const long gi = j / ((long)C * K), ck = j - gi * (long)C * K;
+        const float *src = partial + ((size_t)gi * 4 + p) * C * K + ck;
+        int bsp = 0;
+        for (; bsp + 1 < nsplit; bsp += 2) {
+            s0 += (double)src[(size_t)bsp * per];
+            s1 += (double)src[(size_t)(bsp + 1) * per];
+        }
+        if (bsp < nsplit) s0 += (double)src[(size_t)bsp * per];
+    }
+    red[p][e] = s0 + s1;
+    __syncthreads();
+    if (p != 0 || j >= nout) return;
+    const double m0 = red[0][e], m1 = red[1][e], m2 = red[2][e], m3 = red[3][e];
+    const long gi = j / ((long)C * K), ck = j - gi * (long)C * K;
+    const int c = (int)(ck / K), k = (int)(ck - (long)c * K);
+    float *o = dw + ((size_t)k * C + c) * 27 + gi * 3;
+    o[0] = (float)(m0 + 0.5 * (m1 + m2));
+    o[1] = (float)(0.5 * (m1 - m2));
+    o[2] = (float)(0.5 * (m1 + m2) + m3);
+}
+
 // ------------------------------------------------------------------------------------------------ narrow-input wgrad
 // C <= 8 with ntaps*C <= 128 (the 4-modality input layer: 27 taps x 4 channels = 108 rows).  Padding C to a 32-row M
 // tile per tap wastes 7/8 of the MFMAs; here the GEMM M index is the (tap, channel) pair: wave w owns rows
@@ -1321,6 +1568,34 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         const long per16 = (long)g.ntaps * C * g.K;
         hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per16, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
         return check_launch("conv wgrad reduce (bf16 mfma)");
+    }
+    static const int wino_off = getenv("MVD_WINO") ? (atoi(getenv("MVD_WINO")) == 0) : 0;
+    if (!bf16_in && !wino_off && cfg == 0 && g.ntaps == 27 && g.T == 27 && !g.transposed_out && g.C1 % 32 == 0 &&
+        g.C2 % 32 == 0 && g.K % 32 == 0 && tg.TD == 2) {
+        bool plain = true;
+        for (int a = 0; a < 3; a++) plain = plain && g.sa[a] == 1 && g.sb[a] == 1;
+        for (int t = 0; t < 27 && plain; t++)
+            plain = g.wt[t] == t && g.off[t][0] == t / 9 - 1 && g.off[t][1] == (t / 3) % 3 - 1 && g.off[t][2] == t % 3 - 1 &&
+                    g.ob[t][0] == 0 && g.ob[t][1] == 0 && g.ob[t][2] == 0;
+        const size_t need_w = (size_t)tg.nsplit * 36 * C * g.K * sizeof(float);
+        if (plain && need_w <= ws_bytes) {
+            // Winograd F(2,3)-transposed weight gradient: 36 position tiles over pairs instead of 27 taps over voxels
+            auto kern = tg.TW == 8 ? k_wgrad_wino<13, 4, 4> : k_wgrad_wino<13, 4, 2>;
+            static bool cfgd_w[2] = {false, false};
+            if (!cfgd_w[tg.TW == 8]) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_LIMIT) != hipSuccess) {
+                    set_error("conv wgrad (winograd): cannot raise the dynamic LDS limit");
+                    return 1;
+                }
+                cfgd_w[tg.TW == 8] = true;
+            }
+            hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)(13 + 4) * 4096, s, g, tg, a1, a2, b, partial);
+            if (check_launch("conv wgrad (winograd)")) return 1;
+            hipLaunchKernelGGL(k_wgrad_reduce_wino, dim3(cdiv((long)9 * C * g.K, 64)), dim3(256), 0, s, partial, dw, C, g.K,
+                               tg.nsplit);
+            return check_launch("conv wgrad reduce (winograd)");
+        }
     }
     if (cfg == 0 && sameB && g.C2 == 0 && C <= 8 && C % 4 == 0 && g.ntaps * C <= 128 && tg.nslotsA * (C / 4) <= 2 * 256) {
         // narrow-input layer: rows of the GEMM are (tap, channel) pairs
