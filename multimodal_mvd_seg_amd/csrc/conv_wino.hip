@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
             const int gz = gi / 3, gy = gi - gz * 3;
             const float4 *px = reinterpret_cast<const float4 *>(xlane + (size_t)((gz * tg.EH + gy) * tg.EW) * WXS);
             float4 s0[4], s1[4], s2[4];  // ph = 0: d0, d1, d2;  ph = 1: d1, d2, d3
+            float4 vv[2][4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 s0[e] = px[e];
@@ -186,26 +187,26 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
                     for (int e = 0; e < 4; e++)
                         wb[pp ^ 1][e] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + e * uq);
                 }
-                float4 vv[4];
+                // (vv is double-buffered over pp: rewriting an operand register right behind the MFMA that reads it stalls)
                 if (ph == 0) {  // wave-uniform: p0 = d0 - d2, p1 = d1 + d2
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        vv[e] = pp == 0 ? make_float4(s0[e].x - s2[e].x, s0[e].y - s2[e].y, s0[e].z - s2[e].z, s0[e].w - s2[e].w)
+                        vv[pp][e] = pp == 0 ? make_float4(s0[e].x - s2[e].x, s0[e].y - s2[e].y, s0[e].z - s2[e].z, s0[e].w - s2[e].w)
                                         : make_float4(s1[e].x + s2[e].x, s1[e].y + s2[e].y, s1[e].z + s2[e].z, s1[e].w + s2[e].w);
                 } else {        // p2 = d2 - d1, p3 = d1 - d3
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        vv[e] = pp == 0 ? make_float4(s1[e].x - s0[e].x, s1[e].y - s0[e].y, s1[e].z - s0[e].z, s1[e].w - s0[e].w)
+                        vv[pp][e] = pp == 0 ? make_float4(s1[e].x - s0[e].x, s1[e].y - s0[e].y, s1[e].z - s0[e].z, s1[e].w - s0[e].w)
                                         : make_float4(s0[e].x - s2[e].x, s0[e].y - s2[e].y, s0[e].z - s2[e].z, s0[e].w - s2[e].w);
                 }
                 if (!(tg.dbg & 2)) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const float4 bq = wb[pp][e];
-                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].x, bq.x, acc[pp], 0, 0, 0);
-                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].y, bq.y, acc[pp], 0, 0, 0);
-                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].z, bq.z, acc[pp], 0, 0, 0);
-                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e].w, bq.w, acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[pp][e].x, bq.x, acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[pp][e].y, bq.y, acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[pp][e].z, bq.z, acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[pp][e].w, bq.w, acc[pp], 0, 0, 0);
                     }
                 }
             }
