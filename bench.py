@@ -62,8 +62,9 @@ def dominant_kernel_roofline(torch, dev):
     implicit GEMM on the most expensive layer (decoder stage 5 conv 0: 64 -> 32 channels at 128^3, two input
     pointers = the eliminated torch.cat), batch 2, through the same entry point ops.Conv3dFn calls.
     ALGORITHMIC flops = 2*27*C_in*C_out*N_out: the direct-convolution count.  The kernel is the Winograd
-    F(2,3)-along-W engine, which EXECUTES 2/3 of them on the MFMA pipe (36 instead of 54 multiply-adds per output
-    pair and filter row); `executed_tflops` / `mfma_frac_executed` state that separately."""
+    F(2x2,3x3) engine, which EXECUTES 4/9 of them on the MFMA pipe (12 instead of 27 multiply-adds per output and
+    channel pair), so `achieved` (algorithmic flops / time) can exceed the pipe's peak; `executed_tflops` /
+    `mfma_frac_executed` state what the pipe actually did."""
     from multimodal_mvd_seg_amd import ops
     from multimodal_mvd_seg_amd._lib import call, i3
     import ctypes
@@ -81,7 +82,7 @@ def dominant_kernel_roofline(torch, dev):
     wino = query("mvd_conv_wino_applicable", N, D, H, W, C1, C2, K, i3((3, 3, 3)), i3((1, 1, 1))) & 1
     uf = None
     if wino:
-        uf = torch.empty(36 * (C1 + C2) * K, device=dev)
+        uf = torch.empty(query("mvd_wino_weight_elems", C1 + C2, K), device=dev)
         call("mvd_pack_weight_wino", P(w), P(uf), None, K, C1 + C2, s)
 
     def conv():
@@ -90,13 +91,17 @@ def dominant_kernel_roofline(torch, dev):
     ms = time_kernel(conv, 3, torch)
     flops = 2.0 * 27 * (C1 + C2) * K * N * D * H * W
     conv_tf = flops / (ms * 1e-3) / 1e12
-    exec_tf = conv_tf * (2.0 / 3.0 if wino else 1.0)
+    mode = query("mvd_wino_mode") if wino else 0
+    exec_ratio = {0: 1.0, 1: 2.0 / 3.0, 2: 4.0 / 9.0}[mode]
+    exec_tf = conv_tf * exec_ratio
     alg_bytes = ((C1 + C2) + K) * N * D * H * W * 4.0
     roof = {"kernel": "conv3d_fwd 64->32 @128^3 (fwd-type implicit GEMM, " +
-                      ("Winograd F(2,3) along W: k_fwd_wino)" if wino else "direct: k_fwd32)"),
+                      {0: "direct: k_fwd32)", 1: "Winograd F(2,3) along W: k_fwd_wino)",
+                       2: "Winograd F(2x2,3x3) over H,W: k_fwd_wino2)"}[mode],
             "bound": "mfma", "achieved": round(conv_tf, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-            "executed_tflops": round(exec_tf, 2), "mfma_frac_executed": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "executed_flop_ratio": round(exec_ratio, 4), "executed_tflops": round(exec_tf, 2),
+            "mfma_frac_executed": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": measured_traffic(), "ms_per_launch": round(ms, 3),
             "hbm_view": {"algorithmic_GB": round(alg_bytes / 1e9, 3),
                          "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),

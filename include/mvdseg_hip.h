@@ -62,15 +62,20 @@ int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float
 int mvd_conv3d_dgrad(const float *dy, const float *wb, float *dx1, int C1, float *dx2, int C2, int N, int D, int H,
                      int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream);
 /* wgrad: dw in TORCH layout [K][C1+C2][T], dbias [K] (may be NULL).  Fixed-order split reduction through `ws`. */
-/* Winograd F(2,3)-along-W variants of the two entries above for 3x3x3 stride-1 convs with C % 32 == 0, K % 32 == 0
- * (every conv of the network but the input layer and the strided ones): 2/3 of the multiply-adds of the direct
- * form, fp32 throughout, same results within fp32 round-off (tests: <= 1e-5 relative to fp64).
- * mvd_pack_weight_wino: torch weight [K][C][3][3][3] -> uf (forward) / ub (input gradient), 36*C*K floats each,
- * layout [chunk32][(dz,dy)][position 0..3][lane half][out channel][16].  The *_wino conv entries take the direct
+/* Winograd variants of the two entries above for 3x3x3 stride-1 convs with C % 32 == 0, K % 32 == 0 (every conv of
+ * the network but the input layer and the strided ones): F(2x2,3x3) over H and W -- 4/9 of the multiply-adds of
+ * the direct form (env MVD_WINO=1 selects F(2,3) along W only: 2/3) -- fp32 throughout, same results within fp32
+ * round-off (tests: <= 1e-5 relative to fp64).
+ * mvd_pack_weight_wino: torch weight [K][C][3][3][3] -> uf (forward) / ub (input gradient), mvd_wino_weight_elems(C, K)
+ * floats each, in the MFMA operand order of the active mode.  The *_wino conv entries take the direct
  * packed weights as well and fall back to the direct engines (same results) for shapes the Winograd kernel does
  * not cover (strides, 1x1x1, fewer than 256 work items, uf/ub == NULL). */
 /* bit 0: the forward would use the Winograd kernel, bit 1: the input gradient would (0: skip packing uf/ub) */
 int mvd_conv_wino_applicable(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3], const int stride[3]);
+/* floats in one uf / ub buffer (48*C*K for the default F(2x2,3x3) mode, 36*C*K for F(2,3) along W) */
+size_t mvd_wino_weight_elems(int C, int K);
+/* 0 = direct engines only, 1 = F(2,3) along W, 2 = F(2x2,3x3) over H and W (default; env MVD_WINO) */
+int mvd_wino_mode(void);
 int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream);
 int mvd_conv3d_fwd_wino(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
                         const float *bias, float *y, int N, int D, int H, int W, int K, const int ksize[3],

@@ -34,6 +34,8 @@ SIGNATURES = {
     "mvd_convT3d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mvd_convT3d_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t, _P]),
     "mvd_conv_wino_applicable": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
+    "mvd_wino_mode": (c_int, []),
+    "mvd_wino_weight_elems": (c_size_t, [c_int, c_int]),
     "mvd_pack_weight_wino": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "mvd_conv3d_fwd_wino": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                     c_size_t, _P]),

@@ -8,7 +8,7 @@ namespace mvd {
 static int g_engine_mode = 0;  // 0 auto, 1 scalar only
 // Winograd F(2,3) engine switches (debug): MVD_WINO=0 disables it, MVD_WINO_MIN overrides the minimum number of
 // 128-voxel x 32-channel work items below which the direct engines (which can split the reduction) are used
-static const int g_wino_off = getenv("MVD_WINO") ? (atoi(getenv("MVD_WINO")) == 0) : 0;
+#define g_wino_off (wino_mode() == 0)
 static long g_wino_min_items = getenv("MVD_WINO_MIN") ? atol(getenv("MVD_WINO_MIN")) : 256;
 
 // =============================================================================================== scalar forward-type
@@ -402,6 +402,9 @@ int mvd_conv_wino_applicable(int N, int D, int H, int W, int C1, int C2, int K, 
     const long tiles_b = (long)N * ((D + 3) / 4) * ((H + 3) / 4) * ((W + 7) / 8) * ((C1 + C2) / 32);
     return (tiles_f >= g_wino_min_items ? 1 : 0) | (tiles_b >= g_wino_min_items ? 2 : 0);
 }
+
+size_t mvd_wino_weight_elems(int C, int K) { return wino_weight_elems(C, K); }
+int mvd_wino_mode(void) { return wino_mode(); }
 
 int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream) {
     MVD_REQUIRE(w && (uf || ub) && K > 0 && C > 0, "pack_weight_wino: bad arguments");

@@ -75,6 +75,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
 int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,
              hipStream_t s);
 int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s);
+int wino_mode();                          // MVD_WINO: 0 off, 1 F(2,3) along W, 2 F(2x2,3x3) (default)
+size_t wino_weight_elems(int C, int K);   // floats of one uf / ub buffer in the active mode
 
 // bf16 forward-type engine (conv_bf16.hip): bf16 activations / packed weights, fp32 accumulate, bf16 output
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,

@@ -1569,7 +1569,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per16, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
         return check_launch("conv wgrad reduce (bf16 mfma)");
     }
-    static const int wino_off = getenv("MVD_WINO") ? (atoi(getenv("MVD_WINO")) == 0) : 0;
+    const int wino_off = wino_mode() == 0;
     if (!bf16_in && !wino_off && cfg == 0 && g.ntaps == 27 && g.T == 27 && !g.transposed_out && g.C1 % 32 == 0 &&
         g.C2 % 32 == 0 && g.K % 32 == 0 && tg.TD == 2) {
         bool plain = true;

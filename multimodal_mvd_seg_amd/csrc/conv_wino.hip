@@ -68,7 +68,19 @@ __global__ void k_pack_wino(const float *__restrict__ w, float *__restrict__ uf,
     }
 }
 
+int pack_weight_wino2(const float *w, float *uf, float *ub, int K, int C, hipStream_t s);
+
+// MVD_WINO: 0 = direct engines only, 1 = F(2,3) along W, 2 (default) = F(2x2,3x3) over H and W for the forward-type
+// passes.  The weight gradient uses the F(2,3)-transposed kernel in modes 1 and 2.
+int wino_mode() {
+    static int m = -1;
+    if (m < 0) m = getenv("MVD_WINO") ? atoi(getenv("MVD_WINO")) : 2;
+    return m;
+}
+size_t wino_weight_elems(int C, int K) { return (size_t)(wino_mode() == 2 ? 48 : 36) * C * K; }
+
 int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s) {
+    if (wino_mode() == 2) return pack_weight_wino2(w, uf, ub, K, C, s);
     const long total = (long)36 * C * K;
     hipLaunchKernelGGL(k_pack_wino, dim3(cdiv(total, 256)), dim3(256), 0, s, w, uf, ub, K, C);
     return check_launch("pack_weight_wino");
@@ -240,6 +252,216 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
     }
 }
 
+// ================================================================================================ F(2x2, 3x3) over H and W
+// Two-dimensional variant: for each filter plane dz, a 2x2 output quad reads a 4x4 input patch;
+//     V = B^T d B (16 positions), M_ab[k] += V_ab[c] U_ab[c][k] with U = G g G^T, y = A^T M A
+// -> 3 x 16 channel contractions per 4 outputs = 12 per output instead of 27 (direct) or 18 (F(2,3) along W only).
+// Workgroup = 4 waves on a 4 x 4 x 8 voxel tile = 32 quads = ONE 32-row M tile; wave a owns row a of the 4x4 position
+// grid (4 accumulator tiles).  Per step (plane gz, 4-channel quarter e): 8 ds_read_b128 (two patch rows x four
+// columns), 32 VALU (row transform R = P[ra] +- P[rb], column transform V_b), 16 MFMAs on four independent chains,
+// and the four 16-byte weight quarters of the next step fetched from L2.  The output transform runs the column half
+// in registers (t0 = M_a0 + M_a1 + M_a2, t1 = M_a1 - M_a2 - M_a3), crosses the row half through the freed halo buffer
+// and wave (yr, yc) writes output voxel (yr, yc) of every quad.
+// U2 layout: [cc][gz][a][e4][b][h][k][4], reduce channel c = cc*32 + h*16 + e4*4 + c4
+__host__ __device__ inline size_t u2idx(int K, int cc, int gz, int a, int b, int h, int k, int e) {
+    return ((((((((size_t)cc * 3 + gz) * 4 + a) * 4 + (e >> 2)) * 4 + b) * 2 + h) * K + k) << 2) + (e & 3);
+}
+
+__global__ void k_pack_wino2(const float *__restrict__ w, float *__restrict__ uf, float *__restrict__ ub, int K, int C) {
+    const long total = (long)3 * 16 * C * K;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % K);
+    long r = idx / K;
+    const int c = (int)(r % C);
+    r /= C;
+    const int b = (int)(r & 3), a = (int)((r >> 2) & 3), gz = (int)(r >> 4);
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const float *wp = w + (((size_t)k * C + c) * 27);
+    if (uf) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) s += G[a][i] * G[b][j] * wp[(gz * 3 + i) * 3 + j];
+        uf[u2idx(K, c >> 5, gz, a, b, (c >> 4) & 1, k, c & 15)] = s;
+    }
+    if (ub) {  // input gradient: reduce K, produce C, filter mirrored in all three axes
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) s += G[a][i] * G[b][j] * wp[((2 - gz) * 3 + (2 - i)) * 3 + (2 - j)];
+        ub[u2idx(C, k >> 5, gz, a, b, (k >> 4) & 1, c, k & 15)] = s;
+    }
+}
+
+int pack_weight_wino2(const float *w, float *uf, float *ub, int K, int C, hipStream_t s) {
+    const long total = (long)48 * C * K;
+    hipLaunchKernelGGL(k_pack_wino2, dim3(cdiv(total, 256)), dim3(256), 0, s, w, uf, ub, K, C);
+    return check_launch("pack_weight_wino2");
+}
+
+__device__ inline float4 f4_axpy(float s, const float4 b, const float4 a) {  // a + s*b
+    return make_float4(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y), fmaf(s, b.z, a.z), fmaf(s, b.w, a.w));
+}
+__device__ inline float4 f4_sub(const float4 a, const float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ inline float4 f4_add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const WinoTile tg, const float *__restrict__ a1,
+                                                      const float *__restrict__ a2, const float *__restrict__ u,
+                                                      const float *__restrict__ bias, float *__restrict__ y1,
+                                                      float *__restrict__ y2) {
+    extern __shared__ __attribute__((aligned(16))) float Xs[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= tg.nitems) return;  // whole workgroup
+    unsigned r_ = (unsigned)item;
+    const int kb = (int)(r_ % (unsigned)tg.nkb); r_ /= (unsigned)tg.nkb;
+    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+    const int td_ = (int)(r_ % (unsigned)tg.ntd);
+    const int n = (int)(r_ / (unsigned)tg.ntd);
+
+    const int C = g.C1 + g.C2;
+    const int nch = C >> 5;
+    const int EHW = tg.EH * tg.EW;
+    const int nx = tg.nslots * 8;
+    const int od0 = td_ * 4, oh0 = th_ * 4, ow0 = tw_ * 8;
+    const int iz0 = od0 - 1, iy0 = oh0 - 1, ix0 = ow0 - 1;
+
+    // position row a = wave: R = P[ra] + sg * P[rb]
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+    // quad i: d-plane i >> 3, quad row (i >> 2) & 1, quad column i & 3; patch origin slot
+    const int sbase = ((i >> 3) * tg.EH + 2 * ((i >> 2) & 1)) * tg.EW + 2 * (i & 3);
+    const float4 *xa4 = reinterpret_cast<const float4 *>(Xs + (size_t)(sbase + ra * tg.EW) * WXS + h * 16);
+    const float4 *xb4 = reinterpret_cast<const float4 *>(Xs + (size_t)(sbase + rb * tg.EW) * WXS + h * 16);
+    // weights: step (cc, gz, e) -> block ((cc*3 + gz)*4 + a)*4 + e of 4 quarters (b) x [h][k][4]
+    const size_t uq = (size_t)2 * tg.K * 4;  // floats between the b quarters
+    const size_t ustep = 4 * uq;             // floats between consecutive e steps
+    const float *ulane = u + (((size_t)h * tg.K + kb * 32 + i) << 2) + (size_t)wave * 4 * ustep;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+
+    for (int cc = 0; cc < nch; cc++) {
+        const int c0 = cc * 32;
+        const float *src;
+        int Cs, cofs;
+        if (c0 < g.C1) {
+            src = a1; Cs = g.C1; cofs = c0;
+        } else {
+            src = a2; Cs = g.C2; cofs = c0 - g.C1;
+        }
+        const float *uc = ulane + (size_t)cc * 3 * 16 * ustep;  // 3 planes x 4 position rows x 4 steps
+        float4 wb[2][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) wb[0][b] = *reinterpret_cast<const float4 *>(uc + b * uq);
+        __syncthreads();  // every wave is done with the previous chunk's halo
+        int tid_ = tid;   // see k_fwd_wino: keeps the slot index math out of the MFMA loop's live ranges
+        asm volatile("" : "+v"(tid_));
+        for (int base = 0; base < WXR; base += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = (base + q) * 256 + tid_;
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < nx) {
+                    const int slot = idx >> 3;
+                    const int ez = (slot * tg.magHW) >> 16, rem = slot - ez * EHW;
+                    const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
+                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
+                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        v[q] = *reinterpret_cast<const float4 *>(
+                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid_ & 7) * 4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int idx = (base + q) * 256 + tid_;
+                if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * WXS + (idx & 7) * 4) = v[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int gz = 0; gz < 3; gz++) {
+            const int po = gz * EHW * (WXS / 4);  // float4 offset of the plane
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                {   // next step's weights: (gz, e + 1), (gz + 1, 0); the chunk's last step re-reads its own
+                    const int nxt = (gz == 2 && e == 3) ? gz * 16 + e : (e == 3 ? (gz + 1) * 16 : gz * 16 + e + 1);
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        wb[(e + 1) & 1][b] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + b * uq);
+                }
+                float4 R[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    R[c] = f4_axpy(sg, xb4[po + c * (WXS / 4) + e], xa4[po + c * (WXS / 4) + e]);
+                float4 V[4];
+                V[0] = f4_sub(R[0], R[2]);
+                V[1] = f4_add(R[1], R[2]);
+                V[2] = f4_sub(R[2], R[1]);
+                V[3] = f4_sub(R[1], R[3]);
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].x, wb[e & 1][b].x, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].y, wb[e & 1][b].y, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].z, wb[e & 1][b].z, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].w, wb[e & 1][b].w, acc[b], 0, 0, 0);
+            }
+        }
+    }
+    // output transform.  Column half in registers, row half across the four waves through LDS.
+    f32x16 t0, t1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        t0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+        t1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+    }
+    __syncthreads();  // all MFMA operand reads of the halo are done
+    {
+        float *xo = Xs + (size_t)wave * 2048 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            xo[r * 64] = t0[r];
+            xo[1024 + r * 64] = t1[r];
+        }
+    }
+    __syncthreads();
+    // wave (yr, yc) = (wave >> 1, wave & 1) finishes output voxel (yr, yc) of each quad from column tile t_yc of
+    // position rows {0,1,2} (yr = 0: sum) or {1,2,3} (yr = 1: t[1] - t[2] - t[3])
+    const int yr = wave >> 1, yc = wave & 1;
+    const float *xt = Xs + (size_t)yc * 1024 + lane;
+    const int k = kb * 32 + i;
+    const float bv = bias ? bias[k] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
+                    tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
+        const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
+        const int pi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int od = od0 + (pi >> 3), oh = oh0 + 2 * ((pi >> 2) & 1) + yr, ow = ow0 + 2 * (pi & 3) + yc;
+        if (od < g.Do && oh < g.Ho && ow < g.Wo) {
+            const size_t ov = (((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + ow;
+            if (k < g.K1)
+                y1[ov * g.K1 + k] = val;
+            else
+                y2[ov * g.K2 + (k - g.K1)] = val;
+        }
+    }
+}
+
 // returns -1 when the problem is not a plain 3x3x3 stride-1 gather with 32-multiple channels (caller falls back)
 int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,
              hipStream_t s) {
@@ -286,7 +508,10 @@ int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u,
     tg.nitems = (int)nitems;
     const size_t lds = (size_t)tg.nslots * WXS * sizeof(float);
     const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_fwd_wino, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, u, bias, y1, y2);
+    if (wino_mode() == 2)
+        hipLaunchKernelGGL(k_fwd_wino2, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, u, bias, y1, y2);
+    else
+        hipLaunchKernelGGL(k_fwd_wino, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, u, bias, y1, y2);
     return check_launch("conv fwd (winograd)");
 }
 

@@ -165,8 +165,8 @@ class Conv3dFn(Function):
             uf = None
             if wino:
                 w = weight.detach().contiguous()
-                uf = torch.empty((36 * C * K,), dtype=torch.float32, device=w.device) if wino & 1 else None
-                ub = torch.empty((36 * C * K,), dtype=torch.float32, device=w.device) if wino & 2 else None
+                uf = torch.empty((query("mvd_wino_weight_elems", C, K),), dtype=torch.float32, device=w.device) if wino & 1 else None
+                ub = torch.empty((query("mvd_wino_weight_elems", C, K),), dtype=torch.float32, device=w.device) if wino & 2 else None
                 call("mvd_pack_weight_wino", _p(w), _p(uf), _p(ub), K, C, _stream())
             call("mvd_conv3d_fwd_wino", _p(x1), C1, _p(x2), C2, _p(wf), _p(uf), _p(bias), _p(y), N, D, H, W, K, i3(ks),
                  i3(stride), _p(ws), ws.numel(), _stream())

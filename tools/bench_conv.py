@@ -62,8 +62,8 @@ def main():
         flops = 2.0 * 27 * (C1 + C2) * K * N * So ** 3
         uf = ub = None
         if not bf and args.wino and query("mvd_conv_wino_applicable", N, S, S, S, C1, C2, K, i3((3, 3, 3)), i3((st, st, st))):
-            uf = torch.empty(36 * (C1 + C2) * K, device=dev)
-            ub = torch.empty(36 * (C1 + C2) * K, device=dev)
+            uf = torch.empty(query("mvd_wino_weight_elems", C1 + C2, K), device=dev)
+            ub = torch.empty(query("mvd_wino_weight_elems", C1 + C2, K), device=dev)
             call("mvd_pack_weight_wino", P(w), P(uf), P(ub), K, C1 + C2, s)
         fns = {
             "fwd": (lambda: call("mvd_conv3d_fwd_wino", P(x1), C1, P(x2), C2, P(wf), P(uf), P(bias), P(y), N, S, S, S, K, ks,
