@@ -1061,6 +1061,301 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_wino(const WgradGeom g, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ Winograd wgrad, 2-D
+// F(2x2,3x3)-transposed weight gradient: per filter plane gz and 2x2 output quad,
+//     V = B^T P B (4x4 input patch -> 16 positions), E = A e A^T (2x2 dy quad -> 16 positions),
+//     M_{gz,a,b}[c][k] += V_ab[c] * E_ab[k],   dW[gz] = G^T M[gz] G  (k_wgrad_reduce_wino2, fp64)
+// -> 48 rank-1 updates per quad (4 voxels) = 12 per voxel instead of 27 (direct) or 18 (1-D).  The GEMM k index is the
+// quad (32 per 2x8x8 tile, lane half h = d-plane); wave a owns position row a for the three planes and four columns
+// b: 12 accumulator tiles (192 AGPRs).  R_a[col] = P[ra][col] +- P[rb][col] depends only on the patch column, and
+// neighbouring quads of a row share two columns, so a wave keeps R[3 gz][ring of 4 columns] in registers and fetches
+// two new columns per step (four at a row end) + the 2x2 dy quad, one step ahead; V (12) and E (4) are double
+// buffered so no MFMA operand register is rewritten behind the MFMA that reads it.  The position row a is a
+// template parameter (the kernel switches on the wave index once): every sign is an add/sub and the two patch rows of
+// a column come from one ds_read2st64_b32.  Tile fixed to 2x8x8 voxels (halo 4 x 10 x 10 slots).
+template <int A, int NA, int NB>
+__device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTile &tg, const float *__restrict__ a1,
+                                                 const float *__restrict__ a2, const float *__restrict__ b,
+                                                 float *__restrict__ partial, float *As, float *Bs) {
+    constexpr int RA = A == 0 ? 0 : (A == 2 ? 2 : 1);
+    constexpr int RB = A == 0 ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
+    constexpr int EAW = 10, EAH = 10, EBW = 8, EBH = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y / tg.nkb, kb = blockIdx.y % tg.nkb;
+    const int split = blockIdx.x;
+    const int C = g.C1 + g.C2, K = g.K;
+
+    f32x16 acc[12];  // [gz][b]
+#pragma unroll
+    for (int j = 0; j < 12; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    const int c0 = cb * 32;
+    const float *asrc;
+    int Cs, cofs;
+    if (c0 < g.C1) {
+        asrc = a1; Cs = g.C1; cofs = c0;
+    } else {
+        asrc = a2; Cs = g.C2; cofs = c0 - g.C1;
+    }
+    const int k0 = kb * 32;
+    const int na = tg.nslotsA * 8, nb = tg.nslotsB * 8;
+    const int part = tid & 7;
+
+    int rela[NA], cza[NA], relb[NB], czb[NB];
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx >> 3;
+        const int ez = slot / (EAH * EAW), rem = slot - ez * (EAH * EAW);
+        const int ey = rem / EAW, ex = rem - ey * EAW;
+        rela[u] = ((ez * g.Hi + ey) * g.Wi + ex) * Cs + cofs + part * 4;
+        cza[u] = idx < na ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx >> 3;
+        const int ez = slot / (EBH * EBW), rem = slot - ez * (EBH * EBW);
+        const int ey = rem / EBW, ex = rem - ey * EBW;
+        relb[u] = ((ez * g.Hb + ey) * g.Wb + ex) * K + k0 + part * 4;
+        czb[u] = idx < nb ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+
+    float4 ra[NA], rb[NB];
+    auto load_tile = [&](int tile) {
+        unsigned r_ = (unsigned)tile;
+        const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+        const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+        const int td_ = (int)(r_ % (unsigned)tg.ntd);
+        const int n = (int)(r_ / (unsigned)tg.ntd);
+        const int od0 = td_ * 2, oh0 = th_ * 8, ow0 = tw_ * 8;
+        {
+            const int z0 = od0 - 1, y0 = oh0 - 1, x0 = ow0 - 1;
+            const float *base = asrc + ((((long)n * g.Di + z0) * g.Hi + y0) * g.Wi + x0) * (long)Cs;
+            const bool interior = z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + 4 <= g.Di && y0 + EAH <= g.Hi && x0 + EAW <= g.Wi;
+            if (interior) {
+#pragma unroll
+                for (int u = 0; u < NA; u++) {
+                    ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cza[u] >= 0) ra[u] = *reinterpret_cast<const float4 *>(base + rela[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NA; u++) {
+                    const int id = z0 + (cza[u] >> 16), ih = y0 + ((cza[u] >> 8) & 255), iw = x0 + (cza[u] & 255);
+                    ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cza[u] >= 0 && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        ra[u] = *reinterpret_cast<const float4 *>(base + rela[u]);
+                }
+            }
+        }
+        {
+            const float *base = b + ((((long)n * g.Db + od0) * g.Hb + oh0) * g.Wb + ow0) * (long)K;
+            const bool interior = od0 + 2 <= g.Db && oh0 + EBH <= g.Hb && ow0 + EBW <= g.Wb;
+            if (interior) {
+#pragma unroll
+                for (int u = 0; u < NB; u++) {
+                    rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (czb[u] >= 0) rb[u] = *reinterpret_cast<const float4 *>(base + relb[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NB; u++) {
+                    const int id = od0 + (czb[u] >> 16), ih = oh0 + ((czb[u] >> 8) & 255), iw = ow0 + (czb[u] & 255);
+                    rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (czb[u] >= 0 && id < g.Db && ih < g.Hb && iw < g.Wb)
+                        rb[u] = *reinterpret_cast<const float4 *>(base + relb[u]);
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 256 + tid) * 4) = ra[u];
+#pragma unroll
+        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 256 + tid) * 4) = rb[u];
+    };
+
+    const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
+    const int abase = h * (EAH * EAW * 128) + i * 4;  // lane half's d-plane, lane column
+    const int bbase = h * (EBH * EBW * 128) + i * 4;
+    // R of patch column `col` (halo x index) of quad row hq, plane gz
+    auto fetch_col = [&](int gz, int hq, int col, float &pa, float &pb) {
+        const int ad = abase + ((gz * EAH + 2 * hq) * EAW + col) * 128;
+        pa = *reinterpret_cast<const float *>(Ab + ad + RA * EAW * 128);
+        pb = *reinterpret_cast<const float *>(Ab + ad + RB * EAW * 128);
+    };
+    auto rcomb = [&](float pa, float pb) { return A == 1 ? pa + pb : pa - pb; };
+    auto fetch_e = [&](int hq, int wq, float (&e)[4]) {
+        const int ad = bbase + ((2 * hq) * EBW + 2 * wq) * 128;
+        e[0] = *reinterpret_cast<const float *>(Bb + ad);
+        e[1] = *reinterpret_cast<const float *>(Bb + ad + 128);
+        e[2] = *reinterpret_cast<const float *>(Bb + ad + EBW * 128);
+        e[3] = *reinterpret_cast<const float *>(Bb + ad + EBW * 128 + 128);
+    };
+    // E row a from the dy quad: F = (A e)_a, E_b = (F A^T)_b
+    auto make_E = [&](const float (&e)[4], float (&E)[4]) {
+        const float f0 = A == 0 ? e[0] : (A == 1 ? e[0] + e[2] : (A == 2 ? e[0] - e[2] : -e[2]));
+        const float f1 = A == 0 ? e[1] : (A == 1 ? e[1] + e[3] : (A == 2 ? e[1] - e[3] : -e[3]));
+        E[0] = f0; E[1] = f0 + f1; E[2] = f0 - f1; E[3] = -f1;
+    };
+
+    float R[3][4];      // [gz][column ring: halo column x lives in slot x & 3]
+    float V[2][3][4];   // MFMA A operands, double buffered over the step parity
+    float E[2][4];      // MFMA B operands
+    int tile = split;
+    if (tile < tg.ntiles) load_tile(tile);
+    while (tile < tg.ntiles) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        const int next = tile + tg.nsplit;
+        if (next < tg.ntiles) load_tile(next);
+        // window of the first quad: columns 0..3 of quad row 0, and its dy quad
+        {
+            float e[4];
+            fetch_e(0, 0, e);
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float pa, pb;
+                    fetch_col(gz, 0, c, pa, pb);
+                    R[gz][c] = rcomb(pa, pb);
+                }
+            make_E(e, E[0]);
+#pragma unroll
+            for (int gz = 0; gz < 3; gz++) {
+                V[0][gz][0] = R[gz][0] - R[gz][2];
+                V[0][gz][1] = R[gz][1] + R[gz][2];
+                V[0][gz][2] = R[gz][2] - R[gz][1];
+                V[0][gz][3] = R[gz][1] - R[gz][3];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int hq = 0; hq < 4; hq++) {
+#pragma unroll
+            for (int wq = 0; wq < 4; wq++) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int cur = wq & 1, nxt = cur ^ 1;
+                // the next step: (hq, wq + 1) needs columns 2wq+4, 2wq+5; after the row's last quad the whole window
+                // (columns 0..3) of quad row hq + 1 (the tile's very last step re-reads row hq: unused)
+                const int nhq = wq == 3 ? (hq < 3 ? hq + 1 : hq) : hq;
+                constexpr int NC = 4;  // columns fetched at a row end; 2 otherwise
+                float pa[3][NC], pb[3][NC], e[4];
+#pragma unroll
+                for (int j = 0; j < 12; j++) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[cur][j >> 2][j & 3], E[cur][j & 3], acc[j], 0, 0, 0);
+                    if (j == 0) fetch_e(nhq, wq == 3 ? 0 : wq + 1, e);
+                    if (wq != 3) {
+                        if (j >= 1 && j <= 3) {  // plane j-1: two new columns
+                            fetch_col(j - 1, nhq, 2 * wq + 4, pa[j - 1][0], pb[j - 1][0]);
+                            fetch_col(j - 1, nhq, 2 * wq + 5, pa[j - 1][1], pb[j - 1][1]);
+                        }
+                    } else {
+                        if (j >= 1 && j <= 6) {  // plane (j-1)/2: four columns, two per slot
+                            const int gz = (j - 1) >> 1, c2 = ((j - 1) & 1) * 2;
+                            fetch_col(gz, nhq, c2, pa[gz][c2], pb[gz][c2]);
+                            fetch_col(gz, nhq, c2 + 1, pa[gz][c2 + 1], pb[gz][c2 + 1]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // window update + operands of the next step (VALU only; the MFMAs above read V[cur] / E[cur])
+                make_E(e, E[nxt]);
+#pragma unroll
+                for (int gz = 0; gz < 3; gz++) {
+                    if (wq != 3) {
+                        R[gz][(2 * wq + 4) & 3] = rcomb(pa[gz][0], pb[gz][0]);
+                        R[gz][(2 * wq + 5) & 3] = rcomb(pa[gz][1], pb[gz][1]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) R[gz][c] = rcomb(pa[gz][c], pb[gz][c]);
+                    }
+                    // next quad's patch columns are x = 2*nwq .. 2*nwq+3 with nwq = wq + 1 (or 0)
+                    constexpr int dummy2 = 0;
+                    (void)dummy2;
+                    const int x0 = wq == 3 ? 0 : 2 * wq + 2;
+                    const float r0 = R[gz][x0 & 3], r1 = R[gz][(x0 + 1) & 3], r2 = R[gz][(x0 + 2) & 3], r3 = R[gz][(x0 + 3) & 3];
+                    V[nxt][gz][0] = r0 - r2;
+                    V[nxt][gz][1] = r1 + r2;
+                    V[nxt][gz][2] = r2 - r1;
+                    V[nxt][gz][3] = r1 - r3;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        tile = next;
+    }
+    // partial[split][gz][a][b][c][k]; D layout: col = lane&31 -> k, row -> c
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        float *po = partial + ((((size_t)split * 3 + (j >> 2)) * 4 + A) * 4 + (j & 3)) * C * K;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
+        }
+    }
+}
+
+template <int NA, int NB>
+__global__ __launch_bounds__(256, 1) void k_wgrad_wino2(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+                                                        const float *__restrict__ a2, const float *__restrict__ b,
+                                                        float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;
+    float *Bs = lds + (size_t)NA * 1024;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // one code copy per position row: every wave of the workgroup runs the same trip counts, so the barriers inside
+    // the copies pair up
+    if (wave == 0) wgrad_wino2_body<0, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
+    else if (wave == 1) wgrad_wino2_body<1, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
+    else if (wave == 2) wgrad_wino2_body<2, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
+    else wgrad_wino2_body<3, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
+}
+
+// dw[k][c][gz][i][j] = sum_{a,b} G[a][i] G[b][j] (sum_split M[split][gz][a][b][c][k])   (fp64, fixed order)
+__global__ __launch_bounds__(256) void k_wgrad_reduce_wino2(const float *__restrict__ partial, float *__restrict__ dw,
+                                                            int C, int K, int nsplit) {
+    __shared__ double red[4][3][64];
+    const long CK = (long)C * K;
+    const long per = 48 * CK;   // one split
+    const long nout = 3 * CK;   // (gz, c, k)
+    const int e = threadIdx.x & 63, a = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + e;
+    double m[4] = {0, 0, 0, 0};
+    if (j < nout) {
+        const long gz = j / CK, ck = j - gz * CK;
+        const float *src = partial + ((size_t)(gz * 4 + a) * 4) * CK + ck;
+        for (int sp = 0; sp < nsplit; sp++) {
+#pragma unroll
+            for (int bq = 0; bq < 4; bq++) m[bq] += (double)src[(size_t)sp * per + (size_t)bq * CK];
+        }
+    }
+    // row a of M times G: (M G)_aj
+    red[a][0][e] = m[0] + 0.5 * (m[1] + m[2]);
+    red[a][1][e] = 0.5 * (m[1] - m[2]);
+    red[a][2][e] = 0.5 * (m[1] + m[2]) + m[3];
+    __syncthreads();
+    if (a != 0 || j >= nout) return;
+    const long gz = j / CK, ck = j - gz * CK;
+    const int c = (int)(ck / K), k = (int)(ck - (long)c * K);
+    float *o = dw + ((size_t)k * C + c) * 27 + gz * 9;
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+        const double q0 = red[0][jj][e], q1 = red[1][jj][e], q2 = red[2][jj][e], q3 = red[3][jj][e];
+        o[0 * 3 + jj] = (float)(q0 + 0.5 * (q1 + q2));
+        o[1 * 3 + jj] = (float)(0.5 * (q1 - q2));
+        o[2 * 3 + jj] = (float)(0.5 * (q1 + q2) + q3);
+    }
+}
+
 // dw[k][c][gz][gy][0..2] = G^T (sum_split M[split][g][0..3][c][k])   (fp64 sums in a fixed order)
 __global__ __launch_bounds__(256) void k_wgrad_reduce_wino(const float *__restrict__ partial, float *__restrict__ dw,
                                                            int C, int K, int nsplit) {
@@ -1580,6 +1875,25 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         const size_t need_w = (size_t)tg.nsplit * 36 * C * g.K * sizeof(float);
         if (plain && need_w <= ws_bytes) {
             // Winograd F(2,3)-transposed weight gradient: 36 position tiles over pairs instead of 27 taps over voxels
+            const size_t need_w2 = (size_t)tg.nsplit * 48 * C * g.K * sizeof(float);
+            if (wino_mode() == 2 && tg.TH == 8 && tg.TW == 8 && tg.EAh == 10 && tg.EAw == 10 && tg.EBh == 8 && tg.EBw == 8 &&
+                need_w2 <= ws_bytes) {
+                auto kern2 = k_wgrad_wino2<13, 4>;
+                static bool cfgd_w2 = false;
+                if (!cfgd_w2) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)LDS_LIMIT) != hipSuccess) {
+                        set_error("conv wgrad (winograd 2-D): cannot raise the dynamic LDS limit");
+                        return 1;
+                    }
+                    cfgd_w2 = true;
+                }
+                hipLaunchKernelGGL(kern2, grid, dim3(256), (size_t)(13 + 4) * 4096, s, g, tg, a1, a2, b, partial);
+                if (check_launch("conv wgrad (winograd 2-D)")) return 1;
+                hipLaunchKernelGGL(k_wgrad_reduce_wino2, dim3(cdiv((long)3 * C * g.K, 64)), dim3(256), 0, s, partial, dw, C,
+                                   g.K, tg.nsplit);
+                return check_launch("conv wgrad reduce (winograd 2-D)");
+            }
             auto kern = tg.TW == 8 ? k_wgrad_wino<13, 4, 4> : k_wgrad_wino<13, 4, 2>;
             static bool cfgd_w[2] = {false, false};
             if (!cfgd_w[tg.TW == 8]) {
