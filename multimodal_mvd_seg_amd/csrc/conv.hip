@@ -318,10 +318,12 @@ static int run_fwd(const FwdGeom &g, const float *a1, const float *a2, const flo
 }
 
 static int run_wgrad(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws,
-                     size_t ws_bytes, hipStream_t s) {
+                     size_t ws_bytes, hipStream_t s, float *dbias = nullptr, int *dbias_done = nullptr) {
+    if (dbias_done) *dbias_done = 0;
     if (g_engine_mode == 0) {
-        int r = wgrad_mfma(g, a1, a2, b, dw, ws, ws_bytes, s);
+        int r = wgrad_mfma(g, a1, a2, b, dw, ws, ws_bytes, s, false, dbias, dbias_done);
         if (r >= 0) return r;
+        if (dbias_done) *dbias_done = 0;
     }
     return wgrad_scalar(g, a1, a2, b, dw, ws, ws_bytes, s);
 }
@@ -532,11 +534,11 @@ int mvd_conv3d_wgrad(const float *x1, int C1, const float *x2, int C2, const flo
     MVD_REQUIRE(ws_bytes >= mvd_conv3d_wgrad_workspace_bytes(C1 + C2, K, g.T, N, g.Do, g.Ho, g.Wo),
                 "conv3d_wgrad: workspace too small");
     hipStream_t s = as_stream(stream);
-    if (dbias) {
-        int r = colsum(dy, dbias, (long)N * g.Do * g.Ho * g.Wo, K, ws, s);
-        if (r) return r;
-    }
-    return run_wgrad(g, x1, x2, dy, dw, ws, ws_bytes, s);
+    int dbias_done = 0;
+    int r = run_wgrad(g, x1, x2, dy, dw, ws, ws_bytes, s, dbias, &dbias_done);
+    if (r) return r;
+    if (dbias && !dbias_done) return colsum(dy, dbias, (long)N * g.Do * g.Ho * g.Wo, K, ws, s);  // ws is free again
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ ConvTranspose3d k == s

@@ -68,8 +68,10 @@ size_t wgrad_scalar_ws(const WgradGeom &g);
 int wgrad_scalar(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws,
                  size_t ws_bytes, hipStream_t s);
 size_t wgrad_mfma_ws(const WgradGeom &g);
+// dbias / dbias_done (optional): engines that see every dy value anyway (the 2-D Winograd kernel) also produce the bias
+// gradient and set *dbias_done = 1; otherwise the caller runs the column-sum kernel
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
-               hipStream_t s, bool bf16_in = false);
+               hipStream_t s, bool bf16_in = false, float *dbias = nullptr, int *dbias_done = nullptr);
 
 // fp32 Winograd F(2,3)-along-W engine for plain 3x3x3 stride-1 problems (conv_wino.hip); u = Winograd-domain weights
 int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,

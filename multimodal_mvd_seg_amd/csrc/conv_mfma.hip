@@ -1076,7 +1076,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_wino(const WgradGeom g, const 
 template <int A, int NA, int NB>
 __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTile &tg, const float *__restrict__ a1,
                                                  const float *__restrict__ a2, const float *__restrict__ b,
-                                                 float *__restrict__ partial, float *As, float *Bs) {
+                                                 float *__restrict__ partial, float *__restrict__ pbias, float *As,
+                                                 float *Bs) {
     constexpr int RA = A == 0 ? 0 : (A == 2 ? 2 : 1);
     constexpr int RB = A == 0 ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
     constexpr int EAW = 10, EAH = 10, EBW = 8, EBH = 8;
@@ -1206,6 +1207,10 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     float R[3][4];      // [gz][column ring: halo column x lives in slot x & 3]
     float V[2][3][4];   // MFMA A operands, double buffered over the step parity
     float E[2][4];      // MFMA B operands
+    // bias gradient: wave 0 of the c-block-0 workgroups sees every dy value of its k-block exactly once (the 2x2
+    // quads it fetches for E): per-lane partial sums, reduced over lanes halves / splits by k_dbias_reduce
+    const float bflag = (A == 0 && pbias != nullptr && cb == 0) ? 1.f : 0.f;
+    float bsum = 0.f;
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
     while (tile < tg.ntiles) {
@@ -1227,6 +1232,7 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                     R[gz][c] = rcomb(pa, pb);
                 }
             make_E(e, E[0]);
+            if (A == 0) bsum += bflag * ((e[0] + e[1]) + (e[2] + e[3]));
 #pragma unroll
             for (int gz = 0; gz < 3; gz++) {
                 V[0][gz][0] = R[gz][0] - R[gz][2];
@@ -1268,6 +1274,10 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                 }
                 // window update + operands of the next step (VALU only; the MFMAs above read V[cur] / E[cur])
                 make_E(e, E[nxt]);
+                if (A == 0) {  // the tile's very last fetch is a re-read: not counted
+                    const float fl = (wq == 3 && hq == 3) ? 0.f : bflag;
+                    bsum += fl * ((e[0] + e[1]) + (e[2] + e[3]));
+                }
 #pragma unroll
                 for (int gz = 0; gz < 3; gz++) {
                     if (wq != 3) {
@@ -1302,22 +1312,32 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
             po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
         }
     }
+    if (A == 0 && pbias != nullptr && cb == 0) pbias[((size_t)split * 2 + h) * K + k0 + i] = bsum;
+}
+
+// dbias[k] = sum over splits and lane halves of pbias[split][h][k]   (fp64, fixed order)
+__global__ void k_dbias_reduce(const float *__restrict__ pbias, float *__restrict__ dbias, int K, int nrows) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0;
+    for (int r = 0; r < nrows; r++) s += (double)pbias[(size_t)r * K + k];
+    dbias[k] = (float)s;
 }
 
 template <int NA, int NB>
 __global__ __launch_bounds__(256, 1) void k_wgrad_wino2(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
                                                         const float *__restrict__ a2, const float *__restrict__ b,
-                                                        float *__restrict__ partial) {
+                                                        float *__restrict__ partial, float *__restrict__ pbias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;
     float *Bs = lds + (size_t)NA * 1024;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one code copy per position row: every wave of the workgroup runs the same trip counts, so the barriers inside
     // the copies pair up
-    if (wave == 0) wgrad_wino2_body<0, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
-    else if (wave == 1) wgrad_wino2_body<1, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
-    else if (wave == 2) wgrad_wino2_body<2, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
-    else wgrad_wino2_body<3, NA, NB>(g, tg, a1, a2, b, partial, As, Bs);
+    if (wave == 0) wgrad_wino2_body<0, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+    else if (wave == 1) wgrad_wino2_body<1, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+    else if (wave == 2) wgrad_wino2_body<2, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+    else wgrad_wino2_body<3, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
 }
 
 // dw[k][c][gz][i][j] = sum_{a,b} G[a][i] G[b][j] (sum_split M[split][gz][a][b][c][k])   (fp64, fixed order)
@@ -1732,7 +1752,8 @@ size_t wgrad_mfma_ws(const WgradGeom &g) {
 }
 
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
-               hipStream_t s, bool bf16_in) {
+               hipStream_t s, bool bf16_in, float *dbias, int *dbias_done) {
+    if (dbias_done) *dbias_done = 0;
     if (!wgrad_mfma_ok(g)) return -1;
     if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)b) & 15) return -1;
     if (bf16_in && (g.C1 % 32 != 0 || g.C2 % 32 != 0 || g.K % 32 != 0)) return -1;
@@ -1875,9 +1896,11 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         const size_t need_w = (size_t)tg.nsplit * 36 * C * g.K * sizeof(float);
         if (plain && need_w <= ws_bytes) {
             // Winograd F(2,3)-transposed weight gradient: 36 position tiles over pairs instead of 27 taps over voxels
-            const size_t need_w2 = (size_t)tg.nsplit * 48 * C * g.K * sizeof(float);
+            const size_t need_m2 = (size_t)tg.nsplit * 48 * C * g.K * sizeof(float);
+            const size_t need_w2 = need_m2 + (size_t)tg.nsplit * 2 * g.K * sizeof(float);
             if (wino_mode() == 2 && tg.TH == 8 && tg.TW == 8 && tg.EAh == 10 && tg.EAw == 10 && tg.EBh == 8 && tg.EBw == 8 &&
                 need_w2 <= ws_bytes) {
+                float *pbias = (dbias && dbias_done) ? partial + need_m2 / sizeof(float) : nullptr;
                 auto kern2 = k_wgrad_wino2<13, 4>;
                 static bool cfgd_w2 = false;
                 if (!cfgd_w2) {
@@ -1888,8 +1911,13 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                     }
                     cfgd_w2 = true;
                 }
-                hipLaunchKernelGGL(kern2, grid, dim3(256), (size_t)(13 + 4) * 4096, s, g, tg, a1, a2, b, partial);
+                hipLaunchKernelGGL(kern2, grid, dim3(256), (size_t)(13 + 4) * 4096, s, g, tg, a1, a2, b, partial, pbias);
                 if (check_launch("conv wgrad (winograd 2-D)")) return 1;
+                if (pbias) {
+                    hipLaunchKernelGGL(k_dbias_reduce, dim3(cdiv(g.K, 64)), dim3(64), 0, s, pbias, dbias, g.K, tg.nsplit * 2);
+                    if (check_launch("conv wgrad dbias reduce")) return 1;
+                    *dbias_done = 1;
+                }
                 hipLaunchKernelGGL(k_wgrad_reduce_wino2, dim3(cdiv((long)3 * C * g.K, 64)), dim3(256), 0, s, partial, dw, C,
                                    g.K, tg.nsplit);
                 return check_launch("conv wgrad reduce (winograd 2-D)");
