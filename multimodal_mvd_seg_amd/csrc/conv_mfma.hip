@@ -458,6 +458,199 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
         }
 }
 
+// ------------------------------------------------------------------------------------------------ stride-2 CK = 32 kernel
+// 3x3x3 stride-2 convolutions (the first conv of encoder stages 1..5).  A stride-2 output tile touches an input
+// footprint 8x its own size and every staged voxel feeds only 27/8 taps on average, so the direct form is the right
+// one (no Winograd) and the footprint has to be staged as whole 128-byte lines: the 8-channel-chunk kernel this
+// replaces re-fetched every line four times and ran at 36-45 TFLOP/s.
+//   * workgroup = 4 waves = a 2 x 4 x 8 output tile x 64 output channels; wave w: output plane w & 1, channel half
+//     w >> 1 (one 32 x 32 accumulator tile);
+//   * per 32-channel chunk the 5 x 9 x 17-slot footprint [765 slots][32 ch] is staged once (110 KB with the 36-float
+//     pad: one workgroup per CU);
+//   * the packed weights are read straight from L2 one tap ahead (16 floats per lane and tap), so the tap loop has
+//     no barrier.
+constexpr int SXR = 24;  // float4 per thread: 765 slots x 8 / 256
+constexpr int SXB = 12;  // staging batch (loads in flight per thread)
+__global__ __launch_bounds__(256, 1) void k_fwd32s(const FwdGeom g, const Fwd32Tile tg, const float *__restrict__ a1,
+                                                   const float *__restrict__ a2, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, float *__restrict__ y1,
+                                                   float *__restrict__ y2) {
+    extern __shared__ __attribute__((aligned(16))) float Xs[];
+    constexpr int XS = 36;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= tg.nitems) return;
+    unsigned r_ = (unsigned)item;
+    const int kb = (int)(r_ % (unsigned)tg.nkb); r_ /= (unsigned)tg.nkb;   // 64-channel blocks
+    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+    const int td_ = (int)(r_ % (unsigned)tg.ntd);
+    const int n = (int)(r_ / (unsigned)tg.ntd);
+
+    const int C = g.C1 + g.C2;
+    const int nch = C >> 5;
+    const int EHW = tg.EH * tg.EW;
+    const int nx = tg.nslots * 8;
+    const int od0 = td_ * 2, oh0 = th_ * 4, ow0 = tw_ * 8;
+    const int iz0 = od0 * 2 + tg.min_off[0], iy0 = oh0 * 2 + tg.min_off[1], ix0 = ow0 * 2 + tg.min_off[2];
+    const int dl = wave & 1, kh = wave >> 1;
+    const int sbase = ((2 * dl) * tg.EH + 2 * (i >> 3)) * tg.EW + 2 * (i & 7);
+    const float4 *xlane = reinterpret_cast<const float4 *>(Xs + (size_t)sbase * XS + h * 16);
+    const int kcol = kb * 64 + kh * 32 + i;
+    // packed weights: [cc][t][h][k][16]
+    const float *wlane = w + (((size_t)h * tg.K + kcol) << 4);
+    const size_t wtap = (size_t)2 * tg.K * 16;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+
+    for (int cc = 0; cc < nch; cc++) {
+        const int c0 = cc * 32;
+        const float *src;
+        int Cs, cofs;
+        if (c0 < g.C1) {
+            src = a1; Cs = g.C1; cofs = c0;
+        } else {
+            src = a2; Cs = g.C2; cofs = c0 - g.C1;
+        }
+        const float *wc = wlane + (size_t)cc * g.T * wtap;
+        // weights run three taps ahead of the MFMAs (4-deep register ring): with one wave per SIMD nothing else hides an
+        // L2 round trip
+        float4 wb[4][4];
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) wb[u][e] = *reinterpret_cast<const float4 *>(wc + (size_t)g.wt[u] * wtap + e * 4);
+        __syncthreads();
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        for (int base = 0; base < SXR; base += SXB) {
+            float4 v[SXB];
+#pragma unroll
+            for (int q = 0; q < SXB; q++) {
+                const int idx = (base + q) * 256 + tid_;
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < nx) {
+                    const int slot = idx >> 3;
+                    const int ez = slot / EHW, rem = slot - ez * EHW;
+                    const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
+                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
+                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        v[q] = *reinterpret_cast<const float4 *>(
+                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid_ & 7) * 4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SXB; q++) {
+                const int idx = (base + q) * 256 + tid_;
+                if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * XS + (idx & 7) * 4) = v[q];
+            }
+        }
+        __syncthreads();
+        // activations of tap t+1 are read from LDS into the other half of af[] before tap t's MFMAs are issued: a register
+        // an in-flight MFMA reads is never the target of the next tap's ds_read
+        float4 af[2][4];
+        {
+            const float4 *pa = xlane + (size_t)tg.toff[0] * (XS / 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) af[0][e] = pa[e];
+        }
+        for (int t0 = 0; t0 < 27; t0 += 4) {  // four taps per trip: static ring indices
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + u;
+                if (t < 27) {  // uniform
+                    const int tn = t + 3 < 27 ? t + 3 : 26;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        wb[(u + 3) & 3][e] = *reinterpret_cast<const float4 *>(wc + (size_t)g.wt[tn] * wtap + e * 4);
+                    const float4 *pa = xlane + (size_t)tg.toff[t + 1 < 27 ? t + 1 : 26] * (XS / 4);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) af[(u + 1) & 1][e] = pa[e];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][e].x, wb[u][e].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][e].y, wb[u][e].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][e].z, wb[u][e].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][e].w, wb[u][e].w, acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    const int od = od0 + dl;
+    if (od >= g.Do) return;
+    const float bv = bias ? bias[kcol] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int oh = oh0 + (row >> 3), ow = ow0 + (row & 7);
+        if (oh < g.Ho && ow < g.Wo) {
+            const size_t ov = (((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + ow;
+            const float val = acc[r] + bv;
+            if (kcol < g.K1)
+                y1[ov * g.K1 + kcol] = val;
+            else
+                y2[ov * g.K2 + (kcol - g.K1)] = val;
+        }
+    }
+}
+
+static int num_cus();
+static int launch_fwd32s(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
+                         float *y2, hipStream_t s) {
+    const int K = g.K1 + g.K2;
+    Fwd32Tile tg;
+    memset(&tg, 0, sizeof(tg));
+    int mn[3] = {127, 127, 127}, mx[3] = {-127, -127, -127};
+    for (int t = 0; t < g.ntaps; t++)
+        for (int a = 0; a < 3; a++) {
+            if (g.off[t][a] < mn[a]) mn[a] = g.off[t][a];
+            if (g.off[t][a] > mx[a]) mx[a] = g.off[t][a];
+        }
+    const int T3[3] = {2, 4, 8};
+    int E[3];
+    for (int a = 0; a < 3; a++) {
+        E[a] = (T3[a] - 1) * 2 + (mx[a] - mn[a]) + 1;
+        tg.min_off[a] = mn[a];
+    }
+    tg.EH = E[1]; tg.EW = E[2];
+    tg.nslots = E[0] * E[1] * E[2];
+    if (tg.nslots > SXR * 32) return -1;
+    int m = (1 << 16) / tg.EW + 1;
+    for (int nn = 0; nn < tg.EH * tg.EW; nn++)
+        if (((nn * m) >> 16) != nn / tg.EW) return -1;
+    tg.magW = m;
+    for (int t = 0; t < g.ntaps; t++)
+        tg.toff[t] = ((g.off[t][0] - mn[0]) * tg.EH + (g.off[t][1] - mn[1])) * tg.EW + (g.off[t][2] - mn[2]);
+    tg.ntd = (g.Do + 1) / 2;
+    tg.nth = (g.Ho + 3) / 4;
+    tg.ntw = (g.Wo + 7) / 8;
+    tg.nkb = K / 64;
+    tg.K = K;
+    const long nitems = (long)g.N * tg.ntd * tg.nth * tg.ntw * tg.nkb;
+    if (nitems > (1L << 30)) return -1;
+    tg.nitems = (int)nitems;
+    const size_t lds = (size_t)tg.nslots * 36 * sizeof(float);
+    static bool cfgd = false;
+    if (!cfgd) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd32s), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS_LIMIT) != hipSuccess) {
+            set_error("conv fwd (stride 2): cannot raise the dynamic LDS limit");
+            return 1;
+        }
+        cfgd = true;
+    }
+    const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_fwd32s, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, w, bias, y1, y2);
+    return check_launch("conv fwd (stride 2, CK=32)");
+}
+
 static int num_cus() {
     static int n = 0;
     if (!n) {
@@ -608,6 +801,15 @@ int fwd_mfma(const FwdGeom &g, const float *a1, const float *a2, const float *w,
             if (force_tg == 3) return launch_fwd32<1, 1, 3>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
             if (force_tg == 1) return launch_fwd32<1, 1, 1>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
             return launch_fwd32<1, 1, 2>(g, t32, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+        }
+    }
+    if (LCK == 32 && g.sa[0] == 2 && g.sa[1] == 2 && g.sa[2] == 2 && g.ntaps == 27 && g.T == 27 && K % 64 == 0 &&
+        g.K1 % 64 == 0 && g.so[0] == 1 && g.so[1] == 1 && g.so[2] == 1 && g.oo[0] == 0 && g.oo[1] == 0 && g.oo[2] == 0 &&
+        !(dbg & 8)) {
+        const long items = (long)g.N * ((g.Do + 1) / 2) * ((g.Ho + 3) / 4) * ((g.Wo + 7) / 8) * (K / 64);
+        if (items >= 256) {  // enough workgroups for the chip; the small stages stay on the chunked kernel
+            int r = launch_fwd32s(g, a1, a2, w, bias, y1, y2, s);
+            if (r >= 0) return r;
         }
     }
     // ---- chunked kernel (8- or 4-channel chunks; 8-channel sub-chunks of the 32-layout when LCK == 32)

@@ -91,6 +91,8 @@ def test_conv3d_two_pointer_concat_equals_cat():
     (64, 64, 64, (9, 10, 11), 1, 1),     # ragged tiles, NT=2
     (32, 0, 32, (20, 17, 13), 1, 2),     # NT=1, several tiles per axis, ragged
     (32, 0, 64, (16, 12, 20), 2, 1),     # stride 2 (8-channel sub-chunks of the 32-layout); dgrad parity classes
+    (32, 0, 64, (32, 32, 64), 2, 2),     # stride 2 through the CK=32 strided kernel (>= 256 work items)
+    (64, 0, 128, (30, 34, 66), 2, 1),    # same, two chunks, two k-blocks, ragged tiles and odd output sizes
     (96, 0, 32, (6, 7, 8), (1, 2, 2), 1),  # anisotropic stride
     (4, 0, 32, (10, 9, 8), 1, 2),        # the 4-channel input layer (CK=4)
     (8, 0, 32, (7, 6, 5), 1, 1),         # CK=8 layout
