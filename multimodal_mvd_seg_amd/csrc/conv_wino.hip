@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             for (int q = 0; q < 4; q++) {
                 const int idx = (base + q) * 256 + tid_;
                 v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nx) {
+                if (idx < nx && !(tg.dbg & 1)) {
                     const int slot = idx >> 3;
                     const int ez = (slot * tg.magHW) >> 16, rem = slot - ez * EHW;
                     const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
@@ -398,9 +398,11 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             for (int e = 0; e < 4; e++) {
                 {   // next step's weights: (gz, e + 1), (gz + 1, 0); the chunk's last step re-reads its own
                     const int nxt = (gz == 2 && e == 3) ? gz * 16 + e : (e == 3 ? (gz + 1) * 16 : gz * 16 + e + 1);
+                    if (!(tg.dbg & 4)) {
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        wb[(e + 1) & 1][b] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + b * uq);
+                        for (int b = 0; b < 4; b++)
+                            wb[(e + 1) & 1][b] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + b * uq);
+                    }
                 }
                 float4 R[4];
 #pragma unroll
