@@ -9,6 +9,8 @@ static int g_engine_mode = 0;  // 0 auto, 1 scalar only
 // Winograd F(2,3) engine switches (debug): MVD_WINO=0 disables it, MVD_WINO_MIN overrides the minimum number of
 // 128-voxel x 32-channel work items below which the direct engines (which can split the reduction) are used
 #define g_wino_off (wino_mode() == 0)
+// MVD_TRANSP=0: transposed convs through the gathered-tap engines (debug / A-B)
+static const int g_transp_off = getenv("MVD_TRANSP") ? (atoi(getenv("MVD_TRANSP")) == 0) : 0;
 static long g_wino_min_items = getenv("MVD_WINO_MIN") ? atol(getenv("MVD_WINO_MIN")) : 256;
 
 // =============================================================================================== scalar forward-type
@@ -546,6 +548,10 @@ int mvd_convT3d_fwd(const float *x, const float *wf, const float *bias, float *y
                     const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(x && wf && y && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_fwd: bad arguments");
     for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_fwd: stride must be 1 or 2");
+    if (g_engine_mode == 0 && !g_transp_off) {
+        int r = convT_fwd_direct(x, wf, bias, y, N, D, H, W, C, K, stride, as_stream(stream));
+        if (r >= 0) return r;
+    }
     for (int pd = 0; pd < stride[0]; pd++)
         for (int ph = 0; ph < stride[1]; ph++)
             for (int pw = 0; pw < stride[2]; pw++) {
@@ -574,6 +580,10 @@ int mvd_convT3d_dgrad(const float *dy, const float *wb, float *dx, int N, int D,
                       const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(dy && wb && dx && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_dgrad: bad arguments");
     for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_dgrad: stride must be 1 or 2");
+    if (g_engine_mode == 0 && !g_transp_off) {
+        int r = convT_dgrad_direct(dy, wb, dx, N, D, H, W, C, K, stride, as_stream(stream));
+        if (r >= 0) return r;
+    }
     FwdGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N;

@@ -80,6 +80,12 @@ int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStre
 int wino_mode();                          // MVD_WINO: 0 off, 1 F(2,3) along W, 2 F(2x2,3x3) (default)
 size_t wino_weight_elems(int C, int K);   // floats of one uf / ub buffer in the active mode
 
+// ConvTranspose3d (kernel == stride) as LDS-free GEMMs (conv_transp.hip); -1 = shape not covered
+int convT_fwd_direct(const float *x, const float *wf, const float *bias, float *y, int N, int D, int H, int W, int C, int K,
+                     const int st[3], hipStream_t s);
+int convT_dgrad_direct(const float *dy, const float *wb, float *dx, int N, int D, int H, int W, int C, int K,
+                       const int st[3], hipStream_t s);
+
 // bf16 forward-type engine (conv_bf16.hip): bf16 activations / packed weights, fp32 accumulate, bf16 output
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
              const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s);

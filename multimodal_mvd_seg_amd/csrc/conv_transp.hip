@@ -1,0 +1,233 @@
+// ConvTranspose3d with kernel == stride (the decoder's up-sampling, UNetDecoder.py:56-59): non-overlapping, so it is a
+// plain GEMM per input voxel,
+//     y[n, s*q + p, k] = bias[k] + sum_c x[n, q, c] * w[c][k][p]          (forward: [voxels x C] x [C x T*K])
+//     dx[n, q, c]      = sum_p sum_k dy[n, s*q + p, k] * w[c][k][p]       (input gradient: [voxels x T*K] x [T*K x C])
+// with T = s0*s1*s2 <= 8 positions.  Every activation element is used by exactly one M tile, so nothing is staged in
+// LDS: a lane reads its 16 reduce channels of its voxel (64 contiguous bytes; the two lane halves share a 128-byte
+// line) straight from HBM and its weight fragment (16 floats, packed layout of conv_geom.h) from L2, both one step
+// ahead of the MFMAs; no barrier anywhere.  The gathered-tap engines ran these as T one-tap launches (each re-reading
+// x and writing a strided eighth of y): 3 ms per step for 16 GFLOP; these kernels are bound by the HBM stream.
+#include "common.h"
+#include "conv_geom.h"
+
+namespace mvd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TranspGeom {
+    int N, D, H, W, C, K;  // input dims, reduce / produce channels of the FORWARD op
+    int s[3], T;
+    long NV;               // N*D*H*W input voxels
+};
+
+// output-voxel index of input voxel v at position (0,0,0): two divisions per row, done once per lane row
+__device__ inline long out_base(const TranspGeom &g, unsigned v) {
+    const unsigned t1 = v / (unsigned)g.W, w = v - t1 * (unsigned)g.W;
+    const unsigned t2 = t1 / (unsigned)g.H, h = t1 - t2 * (unsigned)g.H;  // t2 = n*D + d
+    return (((long)t2 * g.s[0]) * (g.H * g.s[1]) + (long)h * g.s[1]) * (g.W * g.s[2]) + (long)w * g.s[2];
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid (ceil(NV / 128), K / 32): wave = 32 input voxels x one 32-wide block of output channels x all T positions
+__global__ __launch_bounds__(256, 2) void k_convT_fwd(const TranspGeom g, const float *__restrict__ x,
+                                                      const float *__restrict__ wf, const float *__restrict__ bias,
+                                                      float *__restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const long vb = ((long)blockIdx.x * 4 + wave) * 32;
+    if (vb >= g.NV) return;  // whole wave (no barriers in this kernel)
+    const int kb = blockIdx.y;
+    const int nch = g.C >> 5;
+    const long v = vb + i < g.NV ? vb + i : g.NV - 1;  // clamp: rows past the end are computed and dropped
+    const float *xl = x + (size_t)v * g.C + h * 16;
+    // packed weights [cc][t][h][k][16]
+    const float *wl = wf + (((size_t)h * g.K + kb * 32 + i) << 4);
+    const size_t wtap = (size_t)2 * g.K * 16;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+
+    float4 a[2][4], b[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        a[0][e] = *reinterpret_cast<const float4 *>(xl + e * 4);
+        b[0][e] = *reinterpret_cast<const float4 *>(wl + e * 4);
+    }
+    for (int cc = 0; cc < nch; cc += 2) {  // two chunks per trip: static operand-buffer indices
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int c = cc + u;
+            if (c < nch) {  // uniform
+                const int cn = c + 1 < nch ? c + 1 : c;
+#pragma unroll
+                for (int e = 0; e < 4; e++) a[u ^ 1][e] = *reinterpret_cast<const float4 *>(xl + (size_t)cn * 32 + e * 4);
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    if (p < g.T) {  // uniform
+                        // next fragment: position p + 1 of this chunk, or position 0 of the next one
+                        const int pn = p + 1 < g.T ? p + 1 : 0;
+                        const int cq = p + 1 < g.T ? c : cn;
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            b[(p + 1) & 1][e] = *reinterpret_cast<const float4 *>(wl + ((size_t)cq * g.T + pn) * wtap + e * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].x, b[p & 1][e].x, acc[p], 0, 0, 0);
+                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].y, b[p & 1][e].y, acc[p], 0, 0, 0);
+                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].z, b[p & 1][e].z, acc[p], 0, 0, 0);
+                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].w, b[p & 1][e].w, acc[p], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int k = kb * 32 + i;
+    const float bv = bias ? bias[k] : 0.f;
+    const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (vb + row < g.NV) {
+            const long ob = out_base(g, (unsigned)(vb + row));
+#pragma unroll
+            for (int p = 0; p < 8; p++)
+                if (p < g.T) {
+                    const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+                    y[(size_t)(ob + ((long)pd * Hy + ph) * Wy + pw) * g.K + k] = acc[p][r] + bv;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ input gradient
+// grid (ceil(NV / 128), ceil(C / 32 / NT)): wave = 32 input voxels x NT 32-wide blocks of input channels; the reduce
+// dimension runs over the T positions and the K/32 chunks of dy
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_convT_dgrad(const TranspGeom g, const float *__restrict__ dy,
+                                                        const float *__restrict__ wb, float *__restrict__ dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const long vb = ((long)blockIdx.x * 4 + wave) * 32;
+    if (vb >= g.NV) return;
+    const int cb0 = blockIdx.y * NT;
+    const int nkc = g.K >> 5, ncb = g.C >> 5;
+    const long v = vb + i < g.NV ? vb + i : g.NV - 1;
+    const long ob = out_base(g, (unsigned)v);
+    const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    // packed weights (reduce K, produce C): [kc][t][h][c][16]
+    const float *wl = wb + (((size_t)h * g.C + cb0 * 32 + i) << 4);
+    const size_t wtap = (size_t)2 * g.C * 16;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+
+    const int nsteps = g.T * nkc;  // step = (position p, chunk kc), kc fastest
+    auto a_ptr = [&](int step) {
+        const int p = step / nkc, kc = step - p * nkc;
+        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+        return dy + (size_t)(ob + ((long)pd * Hy + ph) * Wy + pw) * g.K + kc * 32 + h * 16;
+    };
+    auto b_ptr = [&](int step) {
+        const int p = step / nkc, kc = step - p * nkc;
+        return wl + ((size_t)kc * g.T + p) * wtap;
+    };
+    float4 a[2][4], b[2][NT][4];
+    {
+        const float *pa = a_ptr(0), *pb = b_ptr(0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[0][e] = *reinterpret_cast<const float4 *>(pa + e * 4);
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                b[0][q][e] = (cb0 + q < ncb) ? *reinterpret_cast<const float4 *>(pb + (size_t)q * 512 + e * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int st = s0 + u;
+            if (st < nsteps) {  // uniform
+                const int sn = st + 1 < nsteps ? st + 1 : st;
+                const float *pa = a_ptr(sn), *pb = b_ptr(sn);
+#pragma unroll
+                for (int e = 0; e < 4; e++) a[u ^ 1][e] = *reinterpret_cast<const float4 *>(pa + e * 4);
+#pragma unroll
+                for (int q = 0; q < NT; q++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        b[u ^ 1][q][e] = (cb0 + q < ncb) ? *reinterpret_cast<const float4 *>(pb + (size_t)q * 512 + e * 4)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+#pragma unroll
+                    for (int q = 0; q < NT; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].x, b[u][q][e].x, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NT; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].y, b[u][q][e].y, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NT; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].z, b[u][q][e].z, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < NT; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].w, b[u][q][e].w, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; q++)
+        if (cb0 + q < ncb) {
+            const int c = (cb0 + q) * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (vb + row < g.NV) dx[(size_t)(vb + row) * g.C + c] = acc[q][r];
+            }
+        }
+}
+
+static bool transp_geom(TranspGeom &g, int N, int D, int H, int W, int C, int K, const int st[3]) {
+    g.N = N; g.D = D; g.H = H; g.W = W; g.C = C; g.K = K;
+    for (int a = 0; a < 3; a++) g.s[a] = st[a];
+    g.T = st[0] * st[1] * st[2];
+    g.NV = (long)N * D * H * W;
+    // 32-bit voxel arithmetic inside the kernels
+    return C % 32 == 0 && K % 32 == 0 && g.T <= 8 && g.NV * g.T < (1L << 31) && g.NV > 0;
+}
+
+// return -1: shape not covered (caller uses the gathered-tap engines)
+int convT_fwd_direct(const float *x, const float *wf, const float *bias, float *y, int N, int D, int H, int W, int C, int K,
+                     const int st[3], hipStream_t s) {
+    TranspGeom g;
+    if (!transp_geom(g, N, D, H, W, C, K, st)) return -1;
+    if (((uintptr_t)x | (uintptr_t)wf) & 15) return -1;
+    const long bx = (g.NV + 127) / 128;
+    if (bx > (1L << 30) || K / 32 > 65535) return -1;
+    hipLaunchKernelGGL(k_convT_fwd, dim3((unsigned)bx, K / 32), dim3(256), 0, s, g, x, wf, bias, y);
+    return check_launch("convT fwd (direct GEMM)");
+}
+
+int convT_dgrad_direct(const float *dy, const float *wb, float *dx, int N, int D, int H, int W, int C, int K,
+                       const int st[3], hipStream_t s) {
+    TranspGeom g;
+    if (!transp_geom(g, N, D, H, W, C, K, st)) return -1;
+    if (((uintptr_t)dy | (uintptr_t)wb) & 15) return -1;
+    const long bx = (g.NV + 127) / 128;
+    if (bx > (1L << 30)) return -1;
+    const int ncb = C / 32;
+    if (ncb >= 4 && ncb % 4 == 0) {
+        hipLaunchKernelGGL(k_convT_dgrad<4>, dim3((unsigned)bx, ncb / 4), dim3(256), 0, s, g, dy, wb, dx);
+    } else if (ncb % 2 == 0) {
+        hipLaunchKernelGGL(k_convT_dgrad<2>, dim3((unsigned)bx, ncb / 2), dim3(256), 0, s, g, dy, wb, dx);
+    } else {
+        hipLaunchKernelGGL(k_convT_dgrad<1>, dim3((unsigned)bx, ncb), dim3(256), 0, s, g, dy, wb, dx);
+    }
+    return check_launch("convT dgrad (direct GEMM)");
+}
+
+}  // namespace mvd
