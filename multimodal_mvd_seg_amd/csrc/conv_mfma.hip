@@ -1517,13 +1517,23 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     if (A == 0 && pbias != nullptr && cb == 0) pbias[((size_t)split * 2 + h) * K + k0 + i] = bsum;
 }
 
-// dbias[k] = sum over splits and lane halves of pbias[split][h][k]   (fp64, fixed order)
-__global__ void k_dbias_reduce(const float *__restrict__ pbias, float *__restrict__ dbias, int K, int nrows) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+// dbias[k] = sum over splits and lane halves of pbias[row][k]   (fp64, fixed order).  Block = 64 channels x 16 row
+// groups: group q sums rows q, q+16, ...; the 16 group sums are combined in a fixed order through LDS.
+__global__ __launch_bounds__(1024) void k_dbias_reduce(const float *__restrict__ pbias, float *__restrict__ dbias, int K,
+                                                       int nrows) {
+    __shared__ double red[16][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + e;
     double s = 0;
-    for (int r = 0; r < nrows; r++) s += (double)pbias[(size_t)r * K + k];
-    dbias[k] = (float)s;
+    if (k < K)
+        for (int r = q; r < nrows; r += 16) s += (double)pbias[(size_t)r * K + k];
+    red[q][e] = s;
+    __syncthreads();
+    if (q != 0 || k >= K) return;
+    double t = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) t += red[j][e];
+    dbias[k] = (float)t;
 }
 
 template <int NA, int NB>
@@ -2116,7 +2126,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                 hipLaunchKernelGGL(kern2, grid, dim3(256), (size_t)(13 + 4) * 4096, s, g, tg, a1, a2, b, partial, pbias);
                 if (check_launch("conv wgrad (winograd 2-D)")) return 1;
                 if (pbias) {
-                    hipLaunchKernelGGL(k_dbias_reduce, dim3(cdiv(g.K, 64)), dim3(64), 0, s, pbias, dbias, g.K, tg.nsplit * 2);
+                    hipLaunchKernelGGL(k_dbias_reduce, dim3(cdiv(g.K, 64)), dim3(1024), 0, s, pbias, dbias, g.K, tg.nsplit * 2);
                     if (check_launch("conv wgrad dbias reduce")) return 1;
                     *dbias_done = 1;
                 }

@@ -28,14 +28,20 @@ __device__ inline long out_base(const TranspGeom &g, unsigned v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// grid (ceil(NV / 128), K / 32): wave = 32 input voxels x one 32-wide block of output channels x all T positions
-__global__ __launch_bounds__(256, 2) void k_convT_fwd(const TranspGeom g, const float *__restrict__ x,
+// grid (ceil(NV / 32), K / 32): workgroup = 32 input voxels x one 32-wide block of output channels; its four waves split
+// the T positions (two each for the 2x2x2 up-sampling), so a wave carries 32 accumulator registers and five or more
+// waves per SIMD hide the L2 / HBM round trips of the LDS-free operand fetches (one wave per position set with all 8
+// accumulators ran at 2 waves per SIMD and 1.4 TB/s).  The x rows are re-read by the four waves from L1/L2.
+__global__ __launch_bounds__(256, 4) void k_convT_fwd(const TranspGeom g, const float *__restrict__ x,
                                                       const float *__restrict__ wf, const float *__restrict__ bias,
                                                       float *__restrict__ y) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const long vb = ((long)blockIdx.x * 4 + wave) * 32;
-    if (vb >= g.NV) return;  // whole wave (no barriers in this kernel)
+    const long vb = (long)blockIdx.x * 32;
+    const int ppw = (g.T + 3) >> 2;            // positions per wave
+    const int p0 = wave * ppw;
+    if (p0 >= g.T) return;                     // whole wave (no barriers in this kernel)
     const int kb = blockIdx.y;
     const int nch = g.C >> 5;
     const long v = vb + i < g.NV ? vb + i : g.NV - 1;  // clamp: rows past the end are computed and dropped
@@ -44,18 +50,24 @@ __global__ __launch_bounds__(256, 2) void k_convT_fwd(const TranspGeom g, const 
     const float *wl = wf + (((size_t)h * g.K + kb * 32 + i) << 4);
     const size_t wtap = (size_t)2 * g.K * 16;
 
-    f32x16 acc[8];
+    f32x16 acc[2];
 #pragma unroll
-    for (int p = 0; p < 8; p++)
+    for (int p = 0; p < 2; p++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+    const int np = g.T - p0 < ppw ? g.T - p0 : ppw;  // 1 or 2 (ppw <= 2 since T <= 8)
 
-    float4 a[2][4], b[2][4];
+    float4 a[2][4], b[2][2][4];
+    auto load_b = [&](int c, float4 (&dst)[2][4]) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        a[0][e] = *reinterpret_cast<const float4 *>(xl + e * 4);
-        b[0][e] = *reinterpret_cast<const float4 *>(wl + e * 4);
-    }
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                dst[j][e] = *reinterpret_cast<const float4 *>(wl + ((size_t)c * g.T + p0 + (j < np ? j : 0)) * wtap + e * 4);
+    };
+#pragma unroll
+    for (int e = 0; e < 4; e++) a[0][e] = *reinterpret_cast<const float4 *>(xl + e * 4);
+    load_b(0, b[0]);
     for (int cc = 0; cc < nch; cc += 2) {  // two chunks per trip: static operand-buffer indices
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -64,23 +76,17 @@ __global__ __launch_bounds__(256, 2) void k_convT_fwd(const TranspGeom g, const 
                 const int cn = c + 1 < nch ? c + 1 : c;
 #pragma unroll
                 for (int e = 0; e < 4; e++) a[u ^ 1][e] = *reinterpret_cast<const float4 *>(xl + (size_t)cn * 32 + e * 4);
+                load_b(cn, b[u ^ 1]);
 #pragma unroll
-                for (int p = 0; p < 8; p++) {
-                    if (p < g.T) {  // uniform
-                        // next fragment: position p + 1 of this chunk, or position 0 of the next one
-                        const int pn = p + 1 < g.T ? p + 1 : 0;
-                        const int cq = p + 1 < g.T ? c : cn;
+                for (int e = 0; e < 4; e++) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            b[(p + 1) & 1][e] = *reinterpret_cast<const float4 *>(wl + ((size_t)cq * g.T + pn) * wtap + e * 4);
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].x, b[u][j][e].x, acc[j], 0, 0, 0);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].x, b[p & 1][e].x, acc[p], 0, 0, 0);
-                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].y, b[p & 1][e].y, acc[p], 0, 0, 0);
-                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].z, b[p & 1][e].z, acc[p], 0, 0, 0);
-                            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].w, b[p & 1][e].w, acc[p], 0, 0, 0);
-                        }
-                    }
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].y, b[u][j][e].y, acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].z, b[u][j][e].z, acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e].w, b[u][j][e].w, acc[j], 0, 0, 0);
                 }
             }
         }
@@ -88,17 +94,24 @@ __global__ __launch_bounds__(256, 2) void k_convT_fwd(const TranspGeom g, const 
     const int k = kb * 32 + i;
     const float bv = bias ? bias[k] : 0.f;
     const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    // output row index of THIS lane's voxel (two divisions, once); the accumulator rows a lane holds belong to other
+    // lanes' voxels: fetched by a lane shuffle instead of 32 more divisions (the index math was the kernel's bottleneck)
+    const int ob_own = (int)out_base(g, (unsigned)v);  // < 2^31 (host-checked)
+    int poff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int p = p0 + (j < np ? j : 0);
+        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+        poff[j] = (pd * Hy + ph) * Wy + pw;
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ob = __shfl(ob_own, row, 64);  // lane `row` (lower half) holds voxel vb + row
         if (vb + row < g.NV) {
-            const long ob = out_base(g, (unsigned)(vb + row));
 #pragma unroll
-            for (int p = 0; p < 8; p++)
-                if (p < g.T) {
-                    const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
-                    y[(size_t)(ob + ((long)pd * Hy + ph) * Wy + pw) * g.K + k] = acc[p][r] + bv;
-                }
+            for (int j = 0; j < 2; j++)
+                if (j < np) y[(size_t)(ob + poff[j]) * g.K + k] = acc[j][r] + bv;
         }
     }
 }
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void k_convT_fwd(const TranspGeom g, const 
 // grid (ceil(NV / 128), ceil(C / 32 / NT)): wave = 32 input voxels x NT 32-wide blocks of input channels; the reduce
 // dimension runs over the T positions and the K/32 chunks of dy
 template <int NT>
-__global__ __launch_bounds__(256, 2) void k_convT_dgrad(const TranspGeom g, const float *__restrict__ dy,
+__global__ __launch_bounds__(256, NT == 1 ? 4 : 3) void k_convT_dgrad(const TranspGeom g, const float *__restrict__ dy,
                                                         const float *__restrict__ wb, float *__restrict__ dx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -206,7 +219,7 @@ int convT_fwd_direct(const float *x, const float *wf, const float *bias, float *
     TranspGeom g;
     if (!transp_geom(g, N, D, H, W, C, K, st)) return -1;
     if (((uintptr_t)x | (uintptr_t)wf) & 15) return -1;
-    const long bx = (g.NV + 127) / 128;
+    const long bx = (g.NV + 31) / 32;
     if (bx > (1L << 30) || K / 32 > 65535) return -1;
     hipLaunchKernelGGL(k_convT_fwd, dim3((unsigned)bx, K / 32), dim3(256), 0, s, g, x, wf, bias, y);
     return check_launch("convT fwd (direct GEMM)");
@@ -219,10 +232,10 @@ int convT_dgrad_direct(const float *dy, const float *wb, float *dx, int N, int D
     if (((uintptr_t)dy | (uintptr_t)wb) & 15) return -1;
     const long bx = (g.NV + 127) / 128;
     if (bx > (1L << 30)) return -1;
+    // one 32-channel block per wave (93 registers: five waves per SIMD hide the operand round trips) while dy is re-read
+    // at most 4 times; two blocks per wave for the wide low-resolution stages
     const int ncb = C / 32;
-    if (ncb >= 4 && ncb % 4 == 0) {
-        hipLaunchKernelGGL(k_convT_dgrad<4>, dim3((unsigned)bx, ncb / 4), dim3(256), 0, s, g, dy, wb, dx);
-    } else if (ncb % 2 == 0) {
+    if (ncb > 4 && ncb % 2 == 0) {
         hipLaunchKernelGGL(k_convT_dgrad<2>, dim3((unsigned)bx, ncb / 2), dim3(256), 0, s, g, dy, wb, dx);
     } else {
         hipLaunchKernelGGL(k_convT_dgrad<1>, dim3((unsigned)bx, ncb), dim3(256), 0, s, g, dy, wb, dx);
