@@ -48,6 +48,22 @@ class _Workspace:
         return buf
 
 
+def _take_grad(param):
+    """Direct gradient sink of optim.FlatParams: the tensor to write this parameter's gradient into (its slice of the
+    flat gradient buffer) when it has not been written in this step, else None (-> return the gradient to autograd)."""
+    take = getattr(param, '_mvd_take_grad', None) if param is not None else None
+    t = take() if take is not None else None
+    if t is not None and not (t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda):
+        raise RuntimeError("flat gradient slice must be a contiguous fp32 cuda tensor")
+    return t
+
+
+def _grad_done(param):
+    done = getattr(param, '_mvd_grad_done', None)
+    if done is not None:
+        done()
+
+
 def _is_cl3d(t):
     return t.dim() == 5 and t.is_contiguous(memory_format=CL3D)
 
@@ -171,6 +187,7 @@ class Conv3dFn(Function):
             call("mvd_conv3d_fwd_wino", _p(x1), C1, _p(x2), C2, _p(wf), _p(uf), _p(bias), _p(y), N, D, H, W, K, i3(ks),
                  i3(stride), _p(ws), ws.numel(), _stream())
         ctx.bf = bf
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x1, x2, wb, ub)
         ctx.geom = (N, C1, C2, D, H, W, K, ks, tuple(stride), tuple(od), bias is not None)
         return y
@@ -197,12 +214,20 @@ class Conv3dFn(Function):
                      i3(stride), _p(ws), ws.numel(), _stream())
         if ctx.needs_input_grad[2]:
             T = ks[0] * ks[1] * ks[2]
-            dw = torch.empty((K, C1 + C2, *ks), dtype=torch.float32, device=dev)
-            db = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
+            weight, bias = ctx.params
+            sink_w, sink_b = _take_grad(weight), (_take_grad(bias) if has_bias else None)
+            dw = sink_w if sink_w is not None else torch.empty((K, C1 + C2, *ks), dtype=torch.float32, device=dev)
+            db = (sink_b if sink_b is not None else torch.empty((K,), dtype=torch.float32, device=dev)) if has_bias else None
             nb = query("mvd_conv3d_wgrad_workspace_bytes", C1 + C2, K, T, N, *od)
             ws = _Workspace.get(nb, dev)
             call("mvd_conv3d_wgrad" + sfx, _p(x1), C1, _p(x2), C2, _p(dy), _p(dw), _p(db), N, D, H, W, K, i3(ks), i3(stride),
                  _p(ws), ws.numel(), _stream())
+            if sink_w is not None:
+                dw = None
+                _grad_done(weight)
+            if sink_b is not None:
+                db = None
+                _grad_done(bias)
         return (dx1 if need1 else None), (dx2 if need2 else None), dw, db, None
 
 
@@ -224,6 +249,7 @@ class ConvTranspose3dFn(Function):
         y = empty_cl3d((N, K, D * stride[0], H * stride[1], W * stride[2]), x.device, x.dtype)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K), x.device)
         ctx.bf = bf
+        ctx.params = (weight, bias)
         call("mvd_convT3d_fwd_bf16" if bf else "mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
              _stream())
         ctx.save_for_backward(x, wb)
@@ -246,12 +272,20 @@ class ConvTranspose3dFn(Function):
                  _stream())
         if ctx.needs_input_grad[1]:
             T = stride[0] * stride[1] * stride[2]
-            dw = torch.empty((C, K, *stride), dtype=torch.float32, device=dev)
-            db = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
+            weight, bias = ctx.params
+            sink_w, sink_b = _take_grad(weight), (_take_grad(bias) if has_bias else None)
+            dw = sink_w if sink_w is not None else torch.empty((C, K, *stride), dtype=torch.float32, device=dev)
+            db = (sink_b if sink_b is not None else torch.empty((K,), dtype=torch.float32, device=dev)) if has_bias else None
             nb = query("mvd_convT3d_wgrad_workspace_bytes", C, K, T, N, D, H, W)
             ws = _Workspace.get(nb, dev)
             call("mvd_convT3d_wgrad" + sfx, _p(x), _p(dy), _p(dw), _p(db), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
                  _stream())
+            if sink_w is not None:
+                dw = None
+                _grad_done(weight)
+            if sink_b is not None:
+                db = None
+                _grad_done(bias)
         return dx, dw, db, None
 
 
@@ -282,6 +316,7 @@ class InstanceNormLeakyReLUFn(Function):
         ctx.save_for_backward(x, g, b, mean, rstd)
         ctx.slope = float(slope)
         ctx.yb = yb
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
@@ -292,8 +327,11 @@ class InstanceNormLeakyReLUFn(Function):
         N, C = x.shape[:2]
         V = x[0, 0].numel()
         dx = empty_cl3d(x.shape, x.device, x.dtype)
-        dg = torch.empty((C,), dtype=torch.float32, device=x.device)
-        db = torch.empty((C,), dtype=torch.float32, device=x.device)
+        gamma, beta = ctx.params
+        sink_g = _take_grad(gamma) if ctx.needs_input_grad[1] else None
+        sink_b = _take_grad(beta) if ctx.needs_input_grad[2] else None
+        dg = sink_g if sink_g is not None else torch.empty((C,), dtype=torch.float32, device=x.device)
+        db = sink_b if sink_b is not None else torch.empty((C,), dtype=torch.float32, device=x.device)
         nb = query("mvd_instnorm_workspace_bytes", N, V, C)
         ws = _Workspace.get(nb, x.device)
         if ctx.yb:
@@ -302,6 +340,12 @@ class InstanceNormLeakyReLUFn(Function):
         else:
             call("mvd_instnorm_lrelu_bwd", _p(x), _p(dy), _p(g), _p(b), _p(mean), _p(rstd), _p(dx), _p(dg), _p(db), N, V,
                  C, ctx.slope, _p(ws), ws.numel(), _stream())
+        if sink_g is not None:
+            dg = None
+            _grad_done(gamma)
+        if sink_b is not None:
+            db = None
+            _grad_done(beta)
         return dx, dg, db, None, None, None
 
 

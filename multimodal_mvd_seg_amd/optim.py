@@ -36,6 +36,13 @@ class FlatParams:
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        # direct gradient sink (ops.py): the HIP backward kernels write dW / dbias / dgamma / dbeta straight into this
+        # buffer instead of returning fresh tensors that autograd would add into p.grad with one small torch kernel per
+        # parameter (~1 ms per step).  A parameter can be taken once per step (zero_grad() starts a new step); a second
+        # contribution in the same step goes through autograd's accumulation as before.
+        self.step_id = 0
+        self._written = [-1] * len(self.params)
+        self.listeners = []   # callables(index): "the gradient of parameter index is complete" (BucketedGradReducer)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.flat[o:o + p.numel()].view(p.shape)
@@ -44,11 +51,28 @@ class FlatParams:
         self.attach_grads()
 
     def attach_grads(self):
-        for p, o in zip(self.params, self.offsets):
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            p._mvd_take_grad = self._make_take(i)
+            p._mvd_grad_done = self._make_done(i)
+
+    def _make_take(self, i):
+        def take():
+            if self._written[i] == self.step_id:
+                return None
+            self._written[i] = self.step_id
+            return self.params[i].grad
+        return take
+
+    def _make_done(self, i):
+        def done():
+            for fn in self.listeners:
+                fn(i)
+        return done
 
     def zero_grad(self):
         self.grad.zero_()
+        self.step_id += 1
         self.attach_grads()
 
 

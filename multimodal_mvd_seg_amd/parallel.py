@@ -68,18 +68,25 @@ class BucketedGradReducer:
         if self.world > 1:
             for i, p in enumerate(self.fp.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            # gradients the HIP kernels write straight into the flat buffer never pass through autograd's accumulation
+            listeners = getattr(self.fp, 'listeners', None)
+            if listeners is not None:
+                listeners.append(self._on_ready)
         self.reset()
 
     def reset(self):
         self._pending = [len(idx) for (_, _, idx) in self.buckets]
         self._works = []
 
+    def _on_ready(self, i):
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
     def _make_hook(self, i):
         def hook(_param):
-            b = self.bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
+            self._on_ready(i)
         return hook
 
     def _launch(self, b):
