@@ -80,6 +80,13 @@ int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, voi
 int mvd_conv3d_fwd_wino(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
                         const float *bias, float *y, int N, int D, int H, int W, int K, const int ksize[3],
                         const int stride[3], void *ws, size_t ws_bytes, void *stream);
+/* InstanceNorm statistics epilogue ("optional sum x / sum x^2 epilogue"): as mvd_conv3d_fwd_wino; when the
+ * Winograd kernel runs it also writes per-tile (sum y, sum y^2) per output channel to stats
+ * [N][mvd_conv_stats_tiles(D,H,W)][K][2] floats and sets *stats_done = 1 (0: not produced, run the plain norm). */
+size_t mvd_conv_stats_tiles(int D, int H, int W);
+int mvd_conv3d_fwd_wino_stats(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
+                              const float *bias, float *y, float *stats, int *stats_done, int N, int D, int H, int W,
+                              int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream);
 int mvd_conv3d_dgrad_wino(const float *dy, const float *wb, const float *ub, float *dx1, int C1, float *dx2, int C2, int N,
                           int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
                           void *stream);
@@ -154,6 +161,11 @@ int mvd_instnorm_lrelu_fwd(const float *x, const float *gamma, const float *beta
                            float *rstd, int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes,
                            void *stream);
 /* dx [N,V,C]; dgamma/dbeta [C] (overwritten).  Recomputes z = xhat*gamma+beta from x for the LeakyReLU mask. */
+/* forward with the statistics taken from the producing conv's epilogue (mvd_conv3d_fwd_wino_stats): no pass over x
+ * for mean / variance; everything else as mvd_instnorm_lrelu_fwd */
+int mvd_instnorm_lrelu_fwd_prestats(const float *x, const float *tile_stats, long ntiles, const float *gamma,
+                                    const float *beta, float *y, float *mean, float *rstd, int N, long V, int C, float eps,
+                                    float slope, void *ws, size_t ws_bytes, void *stream);
 int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, const float *beta,
                            const float *mean, const float *rstd, float *dx, float *dgamma, float *dbeta, int N,
                            long V, int C, float slope, void *ws, size_t ws_bytes, void *stream);

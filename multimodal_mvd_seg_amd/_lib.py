@@ -39,12 +39,17 @@ SIGNATURES = {
     "mvd_pack_weight_wino": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "mvd_conv3d_fwd_wino": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                     c_size_t, _P]),
+    "mvd_conv_stats_tiles": (c_size_t, [c_int, c_int, c_int]),
+    "mvd_conv3d_fwd_wino_stats": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                          _I3, _I3, _P, c_size_t, _P]),
     "mvd_conv3d_dgrad_wino": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                       c_size_t, _P]),
     "mvd_conv3d_wgrad_bf16": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                       c_size_t, _P]),
     "mvd_convT3d_wgrad_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _P, c_size_t,
                                        _P]),
+    "mvd_instnorm_lrelu_fwd_prestats": (c_int, [_P, _P, c_long, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, c_float,
+                                                _P, c_size_t, _P]),
     "mvd_instnorm_lrelu_fwd_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, c_float, _P,
                                             c_size_t, _P]),
     "mvd_instnorm_lrelu_bwd_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, _P,

@@ -304,12 +304,15 @@ static void conv_fwd_geom(FwdGeom &g, int N, int D, int H, int W, int C1, int C2
 // u (optional): Winograd-domain weights of mvd_pack_weight_wino for this pass (uf for the forward, ub for the input
 // gradient); used for plain 3x3x3 stride-1 problems with enough tiles to fill the chip, the direct engines otherwise
 static int run_fwd(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
-                   float *y2, void *ws, size_t ws_bytes, hipStream_t s, const float *u = nullptr) {
+                   float *y2, void *ws, size_t ws_bytes, hipStream_t s, const float *u = nullptr, float *stats = nullptr,
+                   int *stats_done = nullptr) {
+    if (stats_done) *stats_done = 0;
     if (g_engine_mode == 0 && u && !g_wino_off) {
         const long tiles = (long)g.N * ((g.Do + 3) / 4) * ((g.Ho + 3) / 4) * ((g.Wo + 7) / 8) * ((g.K1 + g.K2) / 32);
         if (tiles >= g_wino_min_items) {
-            int r = fwd_wino(g, a1, a2, u, bias, y1, y2, s);
+            int r = fwd_wino(g, a1, a2, u, bias, y1, y2, s, stats, stats_done);
             if (r >= 0) return r;
+            if (stats_done) *stats_done = 0;
         }
     }
     if (g_engine_mode == 0) {
@@ -374,13 +377,14 @@ size_t mvd_conv_fwd_workspace_bytes(int N, long out_voxels, int K) { return fwd_
 
 static int conv3d_fwd_impl(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
                            const float *bias, float *y, int N, int D, int H, int W, int K, const int ksize[3],
-                           const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+                           const int stride[3], void *ws, size_t ws_bytes, void *stream, float *stats = nullptr,
+                           int *stats_done = nullptr) {
     MVD_REQUIRE(x1 && wf && y && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_fwd: null pointer / bad channels");
     MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_fwd: bad shape");
     if (check_ks(ksize, stride, "conv3d_fwd")) return 2;
     FwdGeom g;
     conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
-    return run_fwd(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream), uf);
+    return run_fwd(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream), uf, stats, stats_done);
 }
 
 int mvd_conv3d_fwd(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *bias, float *y, int N,
@@ -409,6 +413,17 @@ int mvd_conv_wino_applicable(int N, int D, int H, int W, int C1, int C2, int K, 
 
 size_t mvd_wino_weight_elems(int C, int K) { return wino_weight_elems(C, K); }
 int mvd_wino_mode(void) { return wino_mode(); }
+
+/* InstanceNorm statistics epilogue: tiles per sample of the partial-statistics buffer [N][tiles][K][2] floats */
+size_t mvd_conv_stats_tiles(int D, int H, int W) { return (size_t)((D + 3) / 4) * ((H + 3) / 4) * ((W + 7) / 8); }
+
+int mvd_conv3d_fwd_wino_stats(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
+                              const float *bias, float *y, float *stats, int *stats_done, int N, int D, int H, int W,
+                              int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(stats_done, "conv3d_fwd_wino_stats: stats_done is required");
+    return conv3d_fwd_impl(x1, C1, x2, C2, wf, uf, bias, y, N, D, H, W, K, ksize, stride, ws, ws_bytes, stream, stats,
+                           stats_done);
+}
 
 int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream) {
     MVD_REQUIRE(w && (uf || ub) && K > 0 && C > 0, "pack_weight_wino: bad arguments");

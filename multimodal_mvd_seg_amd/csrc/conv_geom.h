@@ -74,8 +74,10 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                hipStream_t s, bool bf16_in = false, float *dbias = nullptr, int *dbias_done = nullptr);
 
 // fp32 Winograd F(2,3)-along-W engine for plain 3x3x3 stride-1 problems (conv_wino.hip); u = Winograd-domain weights
+// stats / stats_done (optional): the F(2x2,3x3) kernel can also emit per-tile (sum y, sum y^2) per output channel,
+// [n][tile][K][2] floats with tile = 4x4x8-voxel tiles in raster order (the InstanceNorm statistics epilogue)
 int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,
-             hipStream_t s);
+             hipStream_t s, float *stats = nullptr, int *stats_done = nullptr);
 int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s);
 int wino_mode();                          // MVD_WINO: 0 off, 1 F(2,3) along W, 2 F(2x2,3x3) (default)
 size_t wino_weight_elems(int C, int K);   // floats of one uf / ub buffer in the active mode

@@ -311,7 +311,7 @@ __device__ inline float4 f4_add(const float4 a, const float4 b) { return make_fl
 __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const WinoTile tg, const float *__restrict__ a1,
                                                       const float *__restrict__ a2, const float *__restrict__ u,
                                                       const float *__restrict__ bias, float *__restrict__ y1,
-                                                      float *__restrict__ y2) {
+                                                      float *__restrict__ y2, float *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) float Xs[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     const float *xt = Xs + (size_t)yc * 1024 + lane;
     const int k = kb * 32 + i;
     const float bv = bias ? bias[k] : 0.f;
+    float ssum = 0.f, ssq = 0.f;  // InstanceNorm statistics of this tile (optional epilogue)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
@@ -460,13 +461,35 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
                 y1[ov * g.K1 + k] = val;
             else
                 y2[ov * g.K2 + (k - g.K1)] = val;
+            ssum += val;
+            ssq += val * val;
+        }
+    }
+    if (stats != nullptr) {  // block-uniform
+        // sum x, sum x^2 over the tile's (up to 128) voxels per output channel, in a fixed order: lane halves, then waves
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        float *st = Xs + 8192;  // behind the 4 x 2048-float exchange area
+        if (h == 0) {
+            st[(wave * 32 + i) * 2 + 0] = ssum;
+            st[(wave * 32 + i) * 2 + 1] = ssq;
+        }
+        __syncthreads();
+        if (wave == 0 && h == 0) {
+            const float a = (st[i * 2] + st[(32 + i) * 2]) + (st[(64 + i) * 2] + st[(96 + i) * 2]);
+            const float q = (st[i * 2 + 1] + st[(32 + i) * 2 + 1]) + (st[(64 + i) * 2 + 1] + st[(96 + i) * 2 + 1]);
+            const int tile = (td_ * tg.nth + th_) * tg.ntw + tw_;
+            float *o = stats + (((size_t)n * (tg.ntd * tg.nth * tg.ntw) + tile) * tg.K + k) * 2;
+            o[0] = a;
+            o[1] = q;
         }
     }
 }
 
 // returns -1 when the problem is not a plain 3x3x3 stride-1 gather with 32-multiple channels (caller falls back)
 int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,
-             hipStream_t s) {
+             hipStream_t s, float *stats, int *stats_done) {
+    if (stats_done) *stats_done = 0;
     const int C = g.C1 + g.C2, K = g.K1 + g.K2;
     if (!u || g.ntaps != 27 || g.T != 27) return -1;
     if (C % 32 || g.C1 % 32 || g.C2 % 32 || K % 32 || g.K1 % 32 || g.K2 % 32) return -1;
@@ -510,9 +533,11 @@ int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u,
     tg.nitems = (int)nitems;
     const size_t lds = (size_t)tg.nslots * WXS * sizeof(float);
     const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
-    if (wino_mode() == 2)
-        hipLaunchKernelGGL(k_fwd_wino2, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, u, bias, y1, y2);
-    else
+    if (wino_mode() == 2) {
+        float *st = (stats && stats_done && g.K2 == 0) ? stats : nullptr;
+        hipLaunchKernelGGL(k_fwd_wino2, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, u, bias, y1, y2, st);
+        if (st) *stats_done = 1;
+    } else
         hipLaunchKernelGGL(k_fwd_wino, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, u, bias, y1, y2);
     return check_launch("conv fwd (winograd)");
 }

@@ -104,6 +104,27 @@ __global__ void k_in_finalize(const double *__restrict__ partial, float *__restr
     rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// finalize from the conv epilogue's per-tile partials [n][tile][C][2] (fp32 sums of <= 128 values each): one wave per
+// (n, c), fp64 accumulation over the tiles in a fixed order
+__global__ void k_in_finalize_tiles(const float *__restrict__ partial, float *__restrict__ mean, float *__restrict__ rstd,
+                                    int C, long ntiles, long V, float eps) {
+    const int n = blockIdx.y, c = blockIdx.x;
+    double a = 0, q = 0;
+    for (long b = threadIdx.x; b < ntiles; b += 64) {
+        const size_t o = (((size_t)n * ntiles + b) * C + c) * 2;
+        a += (double)partial[o];
+        q += (double)partial[o + 1];
+    }
+    a = wave_sum(a);
+    q = wave_sum(q);
+    if (threadIdx.x != 0) return;
+    const double m = a / (double)V;
+    double var = q / (double)V - m * m;
+    if (var < 0) var = 0;
+    mean[(size_t)n * C + c] = (float)m;
+    rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 template <int VEC>
 __global__ void k_in_apply(const float *__restrict__ x, const float *__restrict__ gamma,
                            const float *__restrict__ beta, const float *__restrict__ mean,
@@ -394,7 +415,8 @@ size_t mvd_instnorm_workspace_bytes(int N, long V, int C) {
 }
 
 static int in_fwd(const float *x, bool xb, const float *gamma, const float *beta, float *y, bool yb, float *mean,
-                  float *rstd, int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes, void *stream) {
+                  float *rstd, int N, long V, int C, float eps, float slope, void *ws, size_t ws_bytes, void *stream,
+                  const float *tile_stats = nullptr, long ntiles = 0) {
     MVD_REQUIRE(x && gamma && beta && y && mean && rstd && ws, "instnorm_fwd: null pointer");
     MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C <= 1024, "instnorm_fwd: bad shape N=%d V=%ld C=%d", N, V, C);
     MVD_REQUIRE(ws_bytes >= mvd_instnorm_workspace_bytes(N, V, C), "instnorm_fwd: workspace too small");
@@ -406,15 +428,21 @@ static int in_fwd(const float *x, bool xb, const float *gamma, const float *beta
     const bool v4 = (C % 4 == 0) && (g.CG * 4 == C);
     MVD_REQUIRE(v4 || !(xb || yb), "instnorm_fwd: bf16 I/O needs C %% 4 == 0");
     dim3 grid(g.nblk, N);
-    if (v4 && xb)
-        hipLaunchKernelGGL((k_in_stats<4, true>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
-    else if (v4)
-        hipLaunchKernelGGL((k_in_stats<4, false>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
-    else
-        hipLaunchKernelGGL((k_in_stats<1, false>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
-    if (check_launch("instnorm stats")) return 1;
-    hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
-    if (check_launch("instnorm finalize")) return 1;
+    if (tile_stats) {
+        // statistics came out of the producing conv's epilogue: no pass over x
+        hipLaunchKernelGGL(k_in_finalize_tiles, dim3(C, N), dim3(64), 0, s, tile_stats, mean, rstd, C, ntiles, V, eps);
+        if (check_launch("instnorm finalize (conv epilogue statistics)")) return 1;
+    } else {
+        if (v4 && xb)
+            hipLaunchKernelGGL((k_in_stats<4, true>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+        else if (v4)
+            hipLaunchKernelGGL((k_in_stats<4, false>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+        else
+            hipLaunchKernelGGL((k_in_stats<1, false>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
+        if (check_launch("instnorm stats")) return 1;
+        hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
+        if (check_launch("instnorm finalize")) return 1;
+    }
     long per_n = V * C / (v4 ? 4 : 1);
     long bx = cdiv(per_n, 256);
     long cap = 4096 / N > 0 ? 4096 / N : 1;
@@ -493,6 +521,13 @@ int mvd_instnorm_lrelu_bwd(const float *x, const float *dy, const float *gamma, 
                            const float *rstd, float *dx, float *dgamma, float *dbeta, int N, long V, int C,
                            float slope, void *ws, size_t ws_bytes, void *stream) {
     return in_bwd(x, false, dy, false, gamma, beta, mean, rstd, dx, dgamma, dbeta, N, V, C, slope, ws, ws_bytes, stream);
+}
+
+int mvd_instnorm_lrelu_fwd_prestats(const float *x, const float *tile_stats, long ntiles, const float *gamma,
+                                    const float *beta, float *y, float *mean, float *rstd, int N, long V, int C, float eps,
+                                    float slope, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(tile_stats && ntiles > 0, "instnorm_fwd_prestats: tile statistics required");
+    return in_fwd(x, false, gamma, beta, y, false, mean, rstd, N, V, C, eps, slope, ws, ws_bytes, stream, tile_stats, ntiles);
 }
 
 int mvd_instnorm_lrelu_fwd_bf16(const void *x, int x_is_bf16, const float *gamma, const float *beta, uint16_t *y,

@@ -184,8 +184,19 @@ class Conv3dFn(Function):
                 uf = torch.empty((query("mvd_wino_weight_elems", C, K),), dtype=torch.float32, device=w.device) if wino & 1 else None
                 ub = torch.empty((query("mvd_wino_weight_elems", C, K),), dtype=torch.float32, device=w.device) if wino & 2 else None
                 call("mvd_pack_weight_wino", _p(w), _p(uf), _p(ub), K, C, _stream())
-            call("mvd_conv3d_fwd_wino", _p(x1), C1, _p(x2), C2, _p(wf), _p(uf), _p(bias), _p(y), N, D, H, W, K, i3(ks),
-                 i3(stride), _p(ws), ws.numel(), _stream())
+            if uf is not None:
+                # the Winograd kernel also emits the per-tile (sum, sum of squares) of its output: the InstanceNorm that
+                # follows (InstanceNormLeakyReLUFn picks them up from the tensor) skips its statistics pass
+                ntiles = query("mvd_conv_stats_tiles", od[0], od[1], od[2])
+                stats = torch.empty((N, ntiles, K, 2), dtype=torch.float32, device=x1.device)
+                done = ctypes.c_int(0)
+                call("mvd_conv3d_fwd_wino_stats", _p(x1), C1, _p(x2), C2, _p(wf), _p(uf), _p(bias), _p(y), _p(stats),
+                     ctypes.byref(done), N, D, H, W, K, i3(ks), i3(stride), _p(ws), ws.numel(), _stream())
+                if done.value:
+                    y._mvd_tile_stats = (stats, ntiles)
+            else:
+                call("mvd_conv3d_fwd_wino", _p(x1), C1, _p(x2), C2, _p(wf), _p(uf), _p(bias), _p(y), N, D, H, W, K, i3(ks),
+                     i3(stride), _p(ws), ws.numel(), _stream())
         ctx.bf = bf
         ctx.params = (weight, bias)
         ctx.save_for_backward(x1, x2, wb, ub)
@@ -307,9 +318,13 @@ class InstanceNormLeakyReLUFn(Function):
         nb = query("mvd_instnorm_workspace_bytes", N, V, C)
         ws = _Workspace.get(nb, x.device)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        pre = getattr(x, '_mvd_tile_stats', None)
         if yb:
             call("mvd_instnorm_lrelu_fwd_bf16", _p(x), int(xb), _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V, C,
                  float(eps), float(slope), _p(ws), ws.numel(), _stream())
+        elif pre is not None and pre[0].shape[0] == N and pre[0].shape[2] == C:
+            call("mvd_instnorm_lrelu_fwd_prestats", _p(x), _p(pre[0]), pre[1], _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V,
+                 C, float(eps), float(slope), _p(ws), ws.numel(), _stream())
         else:
             call("mvd_instnorm_lrelu_fwd", _p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V, C, float(eps),
                  float(slope), _p(ws), ws.numel(), _stream())

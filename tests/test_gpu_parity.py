@@ -165,6 +165,40 @@ def test_conv3d_winograd_engine_vs_torch_fp64(C1, C2, K, sp, N):
     close(d1, outs["direct"][1].cpu(), 1e-5, 1e-5, "dx1 vs direct engine")
 
 
+def test_conv_instnorm_statistics_epilogue_vs_fp64():
+    """The Winograd conv kernel hands per-tile (sum, sum of squares) of its output to the following fused
+    InstanceNorm+LeakyReLU (no statistics pass over the activation).  Ragged tiles; conv -> norm against fp64,
+    forward and backward, and bit-level agreement of the activation's statistics with the plain two-pass norm."""
+    from multimodal_mvd_seg_amd import ops
+    from multimodal_mvd_seg_amd._lib import call
+    g = torch.Generator().manual_seed(21)
+    N, C, K, sp = 2, 32, 64, (9, 10, 13)
+    x = torch.randn(N, C, *sp, generator=g)
+    w = torch.randn(K, C, 3, 3, 3, generator=g) / np.sqrt(27 * C)
+    b = torch.randn(K, generator=g) * 0.1
+    gamma = torch.rand(K, generator=g) + 0.5
+    beta = torch.randn(K, generator=g) * 0.1
+    gy = torch.randn(N, K, *sp, generator=g)
+    xr, wr, br, gr, ber = [t.double().requires_grad_() for t in (x, w, b, gamma, beta)]
+    ref = F.leaky_relu(F.instance_norm(F.conv3d(xr, wr, br, 1, 1), None, None, gr, ber, True, 0.1, 1e-5), 0.01)
+    ref.backward(gy.double())
+    try:
+        call("mvd_set_wino_min_items", 1)
+        gx, gw, gb, gg, gbe = G(x, True), G(w, True), G(b, True), G(gamma, True), G(beta, True)
+        y = ops.Conv3dFn.apply(gx, None, gw, gb, (1, 1, 1))
+        assert getattr(y, "_mvd_tile_stats", None) is not None, "the statistics epilogue did not run"
+        z = ops.InstanceNormLeakyReLUFn.apply(y, gg, gbe, 1e-5, 0.01)
+        z.backward(G(gy))
+        y2 = y.detach().clone()  # no statistics attached: plain two-pass norm
+        z2 = ops.InstanceNormLeakyReLUFn.apply(y2, gg.detach(), gbe.detach(), 1e-5, 0.01)
+    finally:
+        call("mvd_set_wino_min_items", -1)
+    close(z, ref.detach(), 2e-5, 1e-5, "conv+norm output")
+    close(z, z2.cpu(), 2e-6, 1e-6, "epilogue statistics vs two-pass statistics")
+    close(gx.grad, xr.grad, 2e-5 * float(xr.grad.abs().max()), 1e-5, "dx")
+    close(gg.grad, gr.grad, 2e-5 * float(gr.grad.abs().max()), 1e-5, "dgamma")
+
+
 @pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.startswith("convT3d_")))
 def test_convT3d(name):
     from multimodal_mvd_seg_amd import ops
