@@ -153,3 +153,24 @@ def test_mvd_dual_branch_contract():
                                              DATASET_JSON) if torch.cuda.is_available() else None
     assert (trainer.ContrastiveTrainerMI355.__dict__["build_network_architecture"].__func__ is not
             trainer.nnUNetTrainerMI355.__dict__["build_network_architecture"].__func__)
+
+
+def test_flat_params_direct_gradient_sink_semantics():
+    """ops.py writes gradients straight into FlatParams.grad: a parameter's slice can be taken once per step (then
+    autograd accumulation takes over), zero_grad() opens a new step, and listeners hear every completed gradient."""
+    ps = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7))]
+    fp = optim.FlatParams(ps)
+    heard = []
+    fp.listeners.append(heard.append)
+    t0 = ps[0]._mvd_take_grad()
+    assert t0 is not None and t0.data_ptr() == ps[0].grad.data_ptr() and t0.shape == ps[0].shape
+    t0.fill_(2.0)
+    ps[0]._mvd_grad_done()
+    assert heard == [0]
+    assert ps[0]._mvd_take_grad() is None          # second contribution in the same step: not taken
+    assert ps[1]._mvd_take_grad() is not None
+    assert float(fp.grad[:15].sum()) == 30.0       # the write landed in the flat buffer
+    fp.zero_grad()
+    assert float(fp.grad.abs().sum()) == 0.0
+    assert ps[0]._mvd_take_grad() is not None      # new step
+    assert ps[0].grad.data_ptr() == fp.grad.data_ptr()
