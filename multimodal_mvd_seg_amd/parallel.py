@@ -76,12 +76,13 @@ class BucketedGradReducer:
 
     def reset(self):
         self._pending = [len(idx) for (_, _, idx) in self.buckets]
+        self._launched = [False] * len(self.buckets)
         self._works = []
 
     def _on_ready(self, i):
         b = self.bucket_of[i]
         self._pending[b] -= 1
-        if self._pending[b] == 0:
+        if self._pending[b] == 0 and not self._launched[b]:
             self._launch(b)
 
     def _make_hook(self, i):
@@ -91,6 +92,7 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
+        self._launched[b] = True
         buf = self.fp.grad[s:e]
         # async_op=True: the collective runs on the process group's own stream, ordered after the kernels already
         # enqueued on the current stream (the wgrad that produced this bucket); backward continues meanwhile.
@@ -102,9 +104,8 @@ class BucketedGradReducer:
         collectives and averages (DDP semantics: gradient = mean over ranks)."""
         if self.world <= 1:
             return
-        for b, pend in enumerate(self._pending):
-            if pend > 0:
-                self._pending[b] = 0
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:  # parameters without a gradient this step (or counted twice): reduce now
                 self._launch(b)
         for work, _ in self._works:
             work.wait()
