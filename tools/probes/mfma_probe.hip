@@ -1,5 +1,7 @@
 // Micro-probe: issue rate of v_mfma_f32_32x32x2_f32 from ONE wave per SIMD under different operand sources.
-// build: hipcc --offload-arch=gfx950 -O3 -o mfma_probe mfma_probe.hip ; run on the GPU box
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/mfma_probe tools/probes/mfma_probe.hip ; run on the GPU box
+// (results of round 1: const operands 150-155 TFLOP/s; operand rewritten right behind its MFMA 111; double-buffered
+// operand registers 137; LDS value consumed by an FMA right behind its ds_read 77)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
