@@ -104,25 +104,43 @@ __global__ void k_in_finalize(const double *__restrict__ partial, float *__restr
     rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// finalize from the conv epilogue's per-tile partials [n][tile][C][2] (fp32 sums of <= 128 values each): one wave per
-// (n, c), fp64 accumulation over the tiles in a fixed order
-__global__ void k_in_finalize_tiles(const float *__restrict__ partial, float *__restrict__ mean, float *__restrict__ rstd,
-                                    int C, long ntiles, long V, float eps) {
-    const int n = blockIdx.y, c = blockIdx.x;
-    double a = 0, q = 0;
-    for (long b = threadIdx.x; b < ntiles; b += 64) {
-        const size_t o = (((size_t)n * ntiles + b) * C + c) * 2;
-        a += (double)partial[o];
-        q += (double)partial[o + 1];
+// conv-epilogue statistics: per-tile partials [n][tile][C][2] (fp32 sums of <= 128 values each) -> per-block fp64
+// partials [n][b][C][2] in the layout k_in_finalize reads.  Thread = (channel, tile row): consecutive threads read
+// consecutive (sum, sum of squares) pairs of one tile (coalesced); rows are combined through LDS in a fixed order.
+__global__ void k_in_tiles_reduce(const float *__restrict__ tile, double *__restrict__ partial, int C, int CW, int R,
+                                  long ntiles, long chunk) {
+    extern __shared__ double sm[];  // [R][CW][2]
+    const int n = blockIdx.y, b = blockIdx.x, nblk = gridDim.x;
+    const int tc = threadIdx.x % CW, r = threadIdx.x / CW;
+    const long t0 = (long)b * chunk;
+    long t1 = t0 + chunk;
+    if (t1 > ntiles) t1 = ntiles;
+    for (int c0 = 0; c0 < C; c0 += CW) {
+        const int c = c0 + tc;
+        double a = 0, q = 0;
+        if (r < R && c < C)
+            for (long tt = t0 + r; tt < t1; tt += R) {
+                const float2 v = *reinterpret_cast<const float2 *>(tile + (((size_t)n * ntiles + tt) * C + c) * 2);
+                a += (double)v.x;
+                q += (double)v.y;
+            }
+        __syncthreads();
+        if (r < R) {
+            sm[((size_t)r * CW + tc) * 2 + 0] = a;
+            sm[((size_t)r * CW + tc) * 2 + 1] = q;
+        }
+        __syncthreads();
+        if (r == 0 && c < C) {
+            double sa = 0, sq = 0;
+            for (int rr = 0; rr < R; rr++) {
+                sa += sm[((size_t)rr * CW + tc) * 2 + 0];
+                sq += sm[((size_t)rr * CW + tc) * 2 + 1];
+            }
+            const size_t o = (((size_t)n * nblk + b) * C + c) * 2;
+            partial[o] = sa;
+            partial[o + 1] = sq;
+        }
     }
-    a = wave_sum(a);
-    q = wave_sum(q);
-    if (threadIdx.x != 0) return;
-    const double m = a / (double)V;
-    double var = q / (double)V - m * m;
-    if (var < 0) var = 0;
-    mean[(size_t)n * C + c] = (float)m;
-    rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 template <int VEC>
@@ -430,8 +448,17 @@ static int in_fwd(const float *x, bool xb, const float *gamma, const float *beta
     dim3 grid(g.nblk, N);
     if (tile_stats) {
         // statistics came out of the producing conv's epilogue: no pass over x
-        hipLaunchKernelGGL(k_in_finalize_tiles, dim3(C, N), dim3(64), 0, s, tile_stats, mean, rstd, C, ntiles, V, eps);
-        if (check_launch("instnorm finalize (conv epilogue statistics)")) return 1;
+        long nb2 = (ntiles + 63) / 64;
+        if (nb2 > g.nblk) nb2 = g.nblk;  // the workspace holds N * g.nblk * C * 2 doubles
+        if (nb2 > 64) nb2 = 64;
+        const long chunk2 = (ntiles + nb2 - 1) / nb2;
+        nb2 = (ntiles + chunk2 - 1) / chunk2;
+        const int CW = C < 256 ? C : 256, R2 = 256 / CW;
+        hipLaunchKernelGGL(k_in_tiles_reduce, dim3((unsigned)nb2, N), dim3(256), (size_t)R2 * CW * 2 * sizeof(double), s,
+                           tile_stats, partial, C, CW, R2, ntiles, chunk2);
+        if (check_launch("instnorm statistics from conv tiles")) return 1;
+        hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, (int)nb2, V, eps);
+        if (check_launch("instnorm finalize")) return 1;
     } else {
         if (v4 && xb)
             hipLaunchKernelGGL((k_in_stats<4, true>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
