@@ -749,6 +749,10 @@ int mvd_convT3d_fwd_bf16(const uint16_t *x, const uint16_t *wf, const float *bia
                     const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(x && wf && y && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_fwd_bf16: bad arguments");
     for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_fwd_bf16: stride must be 1 or 2");
+    if (!g_transp_off) {
+        int r = convT_fwd_direct16(x, wf, bias, y, N, D, H, W, C, K, stride, as_stream(stream));
+        if (r >= 0) return r;
+    }
     for (int pd = 0; pd < stride[0]; pd++)
         for (int ph = 0; ph < stride[1]; ph++)
             for (int pw = 0; pw < stride[2]; pw++) {
@@ -777,6 +781,10 @@ int mvd_convT3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx,
                       const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(dy && wb && dx && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_dgrad_bf16: bad arguments");
     for (int a = 0; a < 3; a++) MVD_REQUIRE(stride[a] == 1 || stride[a] == 2, "convT3d_dgrad_bf16: stride must be 1 or 2");
+    if (!g_transp_off) {
+        int r = convT_dgrad_direct16(dy, wb, dx, N, D, H, W, C, K, stride, as_stream(stream));
+        if (r >= 0) return r;
+    }
     FwdGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N;

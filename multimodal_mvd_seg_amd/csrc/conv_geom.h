@@ -88,6 +88,11 @@ int convT_fwd_direct(const float *x, const float *wf, const float *bias, float *
 int convT_dgrad_direct(const float *dy, const float *wb, float *dx, int N, int D, int H, int W, int C, int K,
                        const int st[3], hipStream_t s);
 
+int convT_fwd_direct16(const unsigned short *x, const unsigned short *wf, const float *bias, unsigned short *y, int N, int D,
+                       int H, int W, int C, int K, const int st[3], hipStream_t s);
+int convT_dgrad_direct16(const unsigned short *dy, const unsigned short *wb, unsigned short *dx, int N, int D, int H, int W,
+                         int C, int K, const int st[3], hipStream_t s);
+
 // bf16 forward-type engine (conv_bf16.hip): bf16 activations / packed weights, fp32 accumulate, bf16 output
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
              const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s);

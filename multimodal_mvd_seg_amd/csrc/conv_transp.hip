@@ -204,6 +204,151 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 3) void k_convT_dgrad(const Tran
         }
 }
 
+// ================================================================================================ bf16 twins
+// Same two GEMMs on v_mfma_f32_32x32x16_bf16: a 32-channel chunk is two k-steps; lane (i, h) reads the 8 bf16 reduce
+// channels s*16 + h*8 .. +7 of its voxel (16 bytes) and its weight fragment [..][s][h][k][8] of conv_bf16.hip's layout.
+typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
+
+__device__ inline bf16x8t ld_bf8(const unsigned short *p) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(p);
+    return __builtin_bit_cast(bf16x8t, q);
+}
+
+__global__ __launch_bounds__(256, 4) void k_convT_fwd16(const TranspGeom g, const unsigned short *__restrict__ x,
+                                                        const unsigned short *__restrict__ wf,
+                                                        const float *__restrict__ bias, unsigned short *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const long vb = (long)blockIdx.x * 32;
+    const int ppw = (g.T + 3) >> 2;
+    const int p0 = wave * ppw;
+    if (p0 >= g.T) return;
+    const int kb = blockIdx.y;
+    const int nch = g.C >> 5;
+    const long v = vb + i < g.NV ? vb + i : g.NV - 1;
+    const unsigned short *xl = x + (size_t)v * g.C + h * 8;
+    // packed weights [cc][t][s][h][k][8]
+    const unsigned short *wl = wf + (((size_t)h * g.K + kb * 32 + i) << 3);
+    const size_t ws_ = (size_t)2 * g.K * 8;   // elements between k-steps
+    const size_t wtap = 2 * ws_;              // elements between taps
+    f32x16 acc[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[p][r] = 0.f;
+    const int np = g.T - p0 < ppw ? g.T - p0 : ppw;
+    bf16x8t a[2][2], b[2][2][2];  // [buffer][k-step] / [buffer][position][k-step]
+    auto load_ab = [&](int c, int buf) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            a[buf][s2] = ld_bf8(xl + (size_t)c * 32 + s2 * 16);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                b[buf][j][s2] = ld_bf8(wl + ((size_t)c * g.T + p0 + (j < np ? j : 0)) * wtap + s2 * ws_);
+        }
+    };
+    load_ab(0, 0);
+    for (int cc = 0; cc < nch; cc += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int c = cc + u;
+            if (c < nch) {
+                load_ab(c + 1 < nch ? c + 1 : c, u ^ 1);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][s2], b[u][j][s2], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    const int k = kb * 32 + i;
+    const float bv = bias ? bias[k] : 0.f;
+    const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    const int ob_own = (int)out_base(g, (unsigned)v);
+    int poff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int p = p0 + (j < np ? j : 0);
+        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+        poff[j] = (pd * Hy + ph) * Wy + pw;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ob = __shfl(ob_own, row, 64);
+        if (vb + row < g.NV) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                if (j < np) y[(size_t)(ob + poff[j]) * g.K + k] = f2bf(acc[j][r] + bv);
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 4) void k_convT_dgrad16(const TranspGeom g, const unsigned short *__restrict__ dy,
+                                                          const unsigned short *__restrict__ wb,
+                                                          unsigned short *__restrict__ dx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const long vb = ((long)blockIdx.x * 4 + wave) * 32;
+    if (vb >= g.NV) return;
+    const int cb0 = blockIdx.y * NT;
+    const int nkc = g.K >> 5, ncb = g.C >> 5;
+    const long v = vb + i < g.NV ? vb + i : g.NV - 1;
+    const long ob = out_base(g, (unsigned)v);
+    const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    // packed weights (reduce K, produce C): [kc][t][s][h][c][8]
+    const unsigned short *wl = wb + (((size_t)h * g.C + cb0 * 32 + i) << 3);
+    const size_t ws_ = (size_t)2 * g.C * 8, wtap = 2 * ws_;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+    const int nsteps = g.T * nkc;
+    bf16x8t a[2][2], b[2][NT][2];
+    auto load_ab = [&](int step, int buf) {
+        const int p = step / nkc, kc = step - p * nkc;
+        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+        const unsigned short *pa = dy + (size_t)(ob + ((long)pd * Hy + ph) * Wy + pw) * g.K + kc * 32 + h * 8;
+        const unsigned short *pb = wl + ((size_t)kc * g.T + p) * wtap;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            a[buf][s2] = ld_bf8(pa + s2 * 16);
+#pragma unroll
+            for (int q = 0; q < NT; q++)
+                b[buf][q][s2] = ld_bf8(pb + s2 * ws_ + (size_t)(cb0 + q < ncb ? q : 0) * 256);
+        }
+    };
+    load_ab(0, 0);
+    for (int s0 = 0; s0 < nsteps; s0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int st = s0 + u;
+            if (st < nsteps) {
+                load_ab(st + 1 < nsteps ? st + 1 : st, u ^ 1);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                    for (int q = 0; q < NT; q++)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][s2], b[u][q][s2], acc[q], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; q++)
+        if (cb0 + q < ncb) {
+            const int c = (cb0 + q) * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (vb + row < g.NV) dx[(size_t)(vb + row) * g.C + c] = f2bf(acc[q][r]);
+            }
+        }
+}
+
 static bool transp_geom(TranspGeom &g, int N, int D, int H, int W, int C, int K, const int st[3]) {
     g.N = N; g.D = D; g.H = H; g.W = W; g.C = C; g.K = K;
     for (int a = 0; a < 3; a++) g.s[a] = st[a];
@@ -241,6 +386,32 @@ int convT_dgrad_direct(const float *dy, const float *wb, float *dx, int N, int D
         hipLaunchKernelGGL(k_convT_dgrad<1>, dim3((unsigned)bx, ncb), dim3(256), 0, s, g, dy, wb, dx);
     }
     return check_launch("convT dgrad (direct GEMM)");
+}
+
+int convT_fwd_direct16(const unsigned short *x, const unsigned short *wf, const float *bias, unsigned short *y, int N, int D,
+                       int H, int W, int C, int K, const int st[3], hipStream_t s) {
+    TranspGeom g;
+    if (!transp_geom(g, N, D, H, W, C, K, st)) return -1;
+    if (((uintptr_t)x | (uintptr_t)wf) & 15) return -1;
+    const long bx = (g.NV + 31) / 32;
+    if (bx > (1L << 30) || K / 32 > 65535) return -1;
+    hipLaunchKernelGGL(k_convT_fwd16, dim3((unsigned)bx, K / 32), dim3(256), 0, s, g, x, wf, bias, y);
+    return check_launch("convT fwd (bf16 direct GEMM)");
+}
+
+int convT_dgrad_direct16(const unsigned short *dy, const unsigned short *wb, unsigned short *dx, int N, int D, int H, int W,
+                         int C, int K, const int st[3], hipStream_t s) {
+    TranspGeom g;
+    if (!transp_geom(g, N, D, H, W, C, K, st)) return -1;
+    if (((uintptr_t)dy | (uintptr_t)wb) & 15) return -1;
+    const long bx = (g.NV + 127) / 128;
+    if (bx > (1L << 30)) return -1;
+    const int ncb = C / 32;
+    if (ncb > 4 && ncb % 2 == 0)
+        hipLaunchKernelGGL(k_convT_dgrad16<2>, dim3((unsigned)bx, ncb / 2), dim3(256), 0, s, g, dy, wb, dx);
+    else
+        hipLaunchKernelGGL(k_convT_dgrad16<1>, dim3((unsigned)bx, ncb), dim3(256), 0, s, g, dy, wb, dx);
+    return check_launch("convT dgrad (bf16 direct GEMM)");
 }
 
 }  // namespace mvd
