@@ -1275,7 +1275,10 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_wino(const WgradGeom g, const 
 // buffered so no MFMA operand register is rewritten behind the MFMA that reads it.  The position row a is a
 // template parameter (the kernel switches on the wave index once): every sign is an add/sub and the two patch rows of
 // a column come from one ds_read2st64_b32.  Tile fixed to 2x8x8 voxels (halo 4 x 10 x 10 slots).
-template <int A, int NA, int NB>
+// B0 / NBW: the wave owns position columns b = B0 .. B0+NBW-1 (NBW = 4: four waves per workgroup, one per position row;
+// NBW = 2: eight waves, two per row -- half the accumulators per wave, so two waves share a SIMD and cover each
+// other's barrier / LDS waits).  TPB = threads per workgroup (staging loops).
+template <int A, int B0, int NBW, int TPB, int NA, int NB>
 __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTile &tg, const float *__restrict__ a1,
                                                  const float *__restrict__ a2, const float *__restrict__ b,
                                                  float *__restrict__ partial, float *__restrict__ pbias, float *As,
@@ -1289,9 +1292,10 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     const int split = blockIdx.x;
     const int C = g.C1 + g.C2, K = g.K;
 
-    f32x16 acc[12];  // [gz][b]
+    constexpr int NTL = 3 * NBW;
+    f32x16 acc[NTL];  // [gz][b - B0]
 #pragma unroll
-    for (int j = 0; j < 12; j++)
+    for (int j = 0; j < NTL; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 
@@ -1310,7 +1314,7 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     int rela[NA], cza[NA], relb[NB], czb[NB];
 #pragma unroll
     for (int u = 0; u < NA; u++) {
-        const int idx = u * 256 + tid;
+        const int idx = u * TPB + tid;
         const int slot = idx >> 3;
         const int ez = slot / (EAH * EAW), rem = slot - ez * (EAH * EAW);
         const int ey = rem / EAW, ex = rem - ey * EAW;
@@ -1319,7 +1323,7 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     }
 #pragma unroll
     for (int u = 0; u < NB; u++) {
-        const int idx = u * 256 + tid;
+        const int idx = u * TPB + tid;
         const int slot = idx >> 3;
         const int ez = slot / (EBH * EBW), rem = slot - ez * (EBH * EBW);
         const int ey = rem / EBW, ex = rem - ey * EBW;
@@ -1377,9 +1381,9 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 256 + tid) * 4) = ra[u];
+        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * TPB + tid) * 4) = ra[u];
 #pragma unroll
-        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 256 + tid) * 4) = rb[u];
+        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * TPB + tid) * 4) = rb[u];
     };
 
     const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
@@ -1411,7 +1415,7 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     float E[2][4];      // MFMA B operands
     // bias gradient: wave 0 of the c-block-0 workgroups sees every dy value of its k-block exactly once (the 2x2
     // quads it fetches for E): per-lane partial sums, reduced over lanes halves / splits by k_dbias_reduce
-    const float bflag = (A == 0 && pbias != nullptr && cb == 0) ? 1.f : 0.f;
+    const float bflag = (A == 0 && B0 == 0 && pbias != nullptr && cb == 0) ? 1.f : 0.f;
     float bsum = 0.f;
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
@@ -1434,7 +1438,7 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                     R[gz][c] = rcomb(pa, pb);
                 }
             make_E(e, E[0]);
-            if (A == 0) bsum += bflag * ((e[0] + e[1]) + (e[2] + e[3]));
+            if (A == 0 && B0 == 0) bsum += bflag * ((e[0] + e[1]) + (e[2] + e[3]));
 #pragma unroll
             for (int gz = 0; gz < 3; gz++) {
                 V[0][gz][0] = R[gz][0] - R[gz][2];
@@ -1457,17 +1461,21 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                 constexpr int NC = 4;  // columns fetched at a row end; 2 otherwise
                 float pa[3][NC], pb[3][NC], e[4];
 #pragma unroll
-                for (int j = 0; j < 12; j++) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[cur][j >> 2][j & 3], E[cur][j & 3], acc[j], 0, 0, 0);
+                for (int j = 0; j < NTL; j++) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[cur][j / NBW][B0 + j % NBW], E[cur][B0 + j % NBW], acc[j], 0, 0,
+                                                                  0);
                     if (j == 0) fetch_e(nhq, wq == 3 ? 0 : wq + 1, e);
+                    // fetch group of this MFMA slot: 3 groups (one plane each) in a row's interior, 6 (half a plane
+                    // each) at a row end; with 6 MFMAs per step the row-end groups start at slot 0
+                    const int fg = (NTL >= 7 || wq != 3) ? j - 1 : j;
                     if (wq != 3) {
-                        if (j >= 1 && j <= 3) {  // plane j-1: two new columns
-                            fetch_col(j - 1, nhq, 2 * wq + 4, pa[j - 1][0], pb[j - 1][0]);
-                            fetch_col(j - 1, nhq, 2 * wq + 5, pa[j - 1][1], pb[j - 1][1]);
+                        if (fg >= 0 && fg < 3) {  // plane fg: two new columns
+                            fetch_col(fg, nhq, 2 * wq + 4, pa[fg][0], pb[fg][0]);
+                            fetch_col(fg, nhq, 2 * wq + 5, pa[fg][1], pb[fg][1]);
                         }
                     } else {
-                        if (j >= 1 && j <= 6) {  // plane (j-1)/2: four columns, two per slot
-                            const int gz = (j - 1) >> 1, c2 = ((j - 1) & 1) * 2;
+                        if (fg >= 0 && fg < 6) {  // plane fg/2: four columns, two per slot
+                            const int gz = fg >> 1, c2 = (fg & 1) * 2;
                             fetch_col(gz, nhq, c2, pa[gz][c2], pb[gz][c2]);
                             fetch_col(gz, nhq, c2 + 1, pa[gz][c2 + 1], pb[gz][c2 + 1]);
                         }
@@ -1476,7 +1484,7 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                 }
                 // window update + operands of the next step (VALU only; the MFMAs above read V[cur] / E[cur])
                 make_E(e, E[nxt]);
-                if (A == 0) {  // the tile's very last fetch is a re-read: not counted
+                if (A == 0 && B0 == 0) {  // the tile's very last fetch is a re-read: not counted
                     const float fl = (wq == 3 && hq == 3) ? 0.f : bflag;
                     bsum += fl * ((e[0] + e[1]) + (e[2] + e[3]));
                 }
@@ -1506,15 +1514,15 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     }
     // partial[split][gz][a][b][c][k]; D layout: col = lane&31 -> k, row -> c
 #pragma unroll
-    for (int j = 0; j < 12; j++) {
-        float *po = partial + ((((size_t)split * 3 + (j >> 2)) * 4 + A) * 4 + (j & 3)) * C * K;
+    for (int j = 0; j < NTL; j++) {
+        float *po = partial + ((((size_t)split * 3 + j / NBW) * 4 + A) * 4 + B0 + j % NBW) * C * K;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
         }
     }
-    if (A == 0 && pbias != nullptr && cb == 0) pbias[((size_t)split * 2 + h) * K + k0 + i] = bsum;
+    if (A == 0 && B0 == 0 && pbias != nullptr && cb == 0) pbias[((size_t)split * 2 + h) * K + k0 + i] = bsum;
 }
 
 // dbias[k] = sum over splits and lane halves of pbias[row][k]   (fp64, fixed order).  Block = 64 channels x 16 row
@@ -1546,10 +1554,34 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_wino2(const WgradGeom g, const
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one code copy per position row: every wave of the workgroup runs the same trip counts, so the barriers inside
     // the copies pair up
-    if (wave == 0) wgrad_wino2_body<0, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
-    else if (wave == 1) wgrad_wino2_body<1, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
-    else if (wave == 2) wgrad_wino2_body<2, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
-    else wgrad_wino2_body<3, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+    if (wave == 0) wgrad_wino2_body<0, 0, 4, 256, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+    else if (wave == 1) wgrad_wino2_body<1, 0, 4, 256, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+    else if (wave == 2) wgrad_wino2_body<2, 0, 4, 256, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+    else wgrad_wino2_body<3, 0, 4, 256, NA, NB>(g, tg, a1, a2, b, partial, pbias, As, Bs);
+}
+
+// eight-wave variant: wave w owns position row w >> 1 and the columns {0,1} or {2,3}; NA8 / NB8 = float4 per thread of the
+// same LDS tiles staged by 512 threads
+template <int NA8, int NB8>
+__global__ __launch_bounds__(512, 2) void k_wgrad_wino2w8(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+                                                          const float *__restrict__ a2, const float *__restrict__ b,
+                                                          float *__restrict__ partial, float *__restrict__ pbias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;
+    float *Bs = lds + (size_t)NA8 * 2048;  // A region: NA8 float4 per thread x 512 threads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#define MVD_W8(AA, BB) wgrad_wino2_body<AA, BB, 2, 512, NA8, NB8>(g, tg, a1, a2, b, partial, pbias, As, Bs)
+    switch (wave) {
+        case 0: MVD_W8(0, 0); break;
+        case 1: MVD_W8(0, 2); break;
+        case 2: MVD_W8(1, 0); break;
+        case 3: MVD_W8(1, 2); break;
+        case 4: MVD_W8(2, 0); break;
+        case 5: MVD_W8(2, 2); break;
+        case 6: MVD_W8(3, 0); break;
+        default: MVD_W8(3, 2); break;
+    }
+#undef MVD_W8
 }
 
 // dw[k][c][gz][i][j] = sum_{a,b} G[a][i] G[b][j] (sum_split M[split][gz][a][b][c][k])   (fp64, fixed order)
@@ -2113,7 +2145,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
             if (wino_mode() == 2 && tg.TH == 8 && tg.TW == 8 && tg.EAh == 10 && tg.EAw == 10 && tg.EBh == 8 && tg.EBw == 8 &&
                 need_w2 <= ws_bytes) {
                 float *pbias = (dbias && dbias_done) ? partial + need_m2 / sizeof(float) : nullptr;
-                auto kern2 = k_wgrad_wino2<13, 4>;
+                static const int w8 = getenv("MVD_WGRAD_W8") ? atoi(getenv("MVD_WGRAD_W8")) : 1;
+                auto kern2 = w8 ? k_wgrad_wino2w8<7, 2> : k_wgrad_wino2<13, 4>;
                 static bool cfgd_w2 = false;
                 if (!cfgd_w2) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2123,7 +2156,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                     }
                     cfgd_w2 = true;
                 }
-                hipLaunchKernelGGL(kern2, grid, dim3(256), (size_t)(13 + 4) * 4096, s, g, tg, a1, a2, b, partial, pbias);
+                hipLaunchKernelGGL(kern2, grid, dim3(w8 ? 512 : 256), w8 ? (size_t)(7 + 2) * 8192 : (size_t)(13 + 4) * 4096, s, g, tg,
+                                   a1, a2, b, partial, pbias);
                 if (check_launch("conv wgrad (winograd 2-D)")) return 1;
                 if (pbias) {
                     hipLaunchKernelGGL(k_dbias_reduce, dim3(cdiv(g.K, 64)), dim3(1024), 0, s, pbias, dbias, g.K, tg.nsplit * 2);
