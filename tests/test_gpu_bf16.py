@@ -319,3 +319,29 @@ def test_feature_kl_bf16_rows(C, T):
     assert ga.grad.dtype == torch.bfloat16 and gb.grad.dtype == torch.bfloat16
     close_bf16(ga.grad, ar.grad, "d student")
     close_bf16(gb.grad, br.grad, "d teacher")
+
+
+def test_cfg5_patch_bf16_step_tracks_fp32():
+    """BASELINE configs[4]: the 6-stage network on the 160x160x128 patch (batch 1 here) in bf16 mixed precision.  Size
+    independent properties: the loss of the bf16 step stays within 1 % of the fp32 step from the same weights, every
+    gradient is finite, and the global gradient norms agree within 10 %."""
+    from multimodal_mvd_seg_amd import trainer
+    from multimodal_mvd_seg_amd.network import set_precision
+    strides = [[1, 1, 1]] + [[2, 2, 2]] * 5
+    plans = trainer.make_plans((160, 160, 128), strides, batch_size=1)
+    ds = {"channel_names": {str(i): str(i) for i in range(4)}, "labels": {"background": 0, "a": 1, "b": 2, "c": 3, "d": 4}}
+    tr = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, ds, device=DEV)
+    torch.manual_seed(0)
+    tr.initialize()
+    batch = tr.dummy_batch
+    out = {}
+    for prec in ("fp32", "bf16"):
+        set_precision(tr.network, prec)
+        tr.optimizer.zero_grad()
+        l = tr.loss(tr.network(batch["data"]), batch["target"])
+        l.backward()
+        g = tr.optimizer.fp.grad
+        assert bool(torch.isfinite(g).all())
+        out[prec] = (float(l), float(g.norm()))
+    assert abs(out["bf16"][0] - out["fp32"][0]) <= 1e-2 * abs(out["fp32"][0]), out
+    assert abs(out["bf16"][1] - out["fp32"][1]) <= 0.1 * out["fp32"][1], out
