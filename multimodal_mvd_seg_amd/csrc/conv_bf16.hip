@@ -196,40 +196,47 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                     for (int m = 0; m < MT; m++)
 #pragma unroll
                         for (int q_ = 0; q_ < NT; q_++)
-                            acc[m][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j & 1][m], bfr[j & 1][q_], acc[m][q_], 0, 0, 0);
+                            acc[m][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j & 1][q_], af[j & 1][m], acc[m][q_], 0, 0, 0);
                 }
             }
         }
     }
-    // epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue.  The MFMA operands are swapped (D^T = W^T X^T): column (lane & 31) = voxel of the M tile, rows = output
+    // channels (r & 3) + 8 * (r >> 2) + 4 * h -- a lane holds 4 x 4 consecutive channels of ONE voxel and stores them as
+    // 8-byte bf16 packets (sixteen 2-byte stores per tile cost more than the tile's MFMAs)
     const int od = od0 + wave;
     if (od >= g.Do) return;
 #pragma unroll
-    for (int m = 0; m < MT; m++)
+    for (int m = 0; m < MT; m++) {
+        const int oh = oh0 + 4 * m + (i >> 3), ow = ow0 + (i & 7);
+        if (oh >= g.Ho || ow >= g.Wo) continue;
+        const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
+        const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                          (ow * g.so[2] + g.oo[2]);
 #pragma unroll
-        for (int q = 0; q < NT; q++) {
-            const int k = kb * KT + q * 32 + i;
-            const float bv = (bias && tg.S == 1) ? bias[k] : 0.f;
+        for (int q = 0; q < NT; q++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int oh = oh0 + 4 * m + (row >> 3), ow = ow0 + (row & 7);
-                if (oh < g.Ho && ow < g.Wo) {
-                    if (tg.S > 1) {
-                        const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
-                        part[(((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k] = acc[m][q][r];
-                    } else {
-                        const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
-                                          (ow * g.so[2] + g.oo[2]);
-                        const unsigned short val = f2bf(acc[m][q][r] + bv);
-                        if (k < g.K1)
-                            y1[ov * g.K1 + k] = val;
-                        else
-                            y2[ov * g.K2 + (k - g.K1)] = val;
+            for (int rg = 0; rg < 4; rg++) {
+                const int k = kb * KT + q * 32 + 8 * rg + 4 * h;
+                if (tg.S > 1) {
+                    *reinterpret_cast<float4 *>(part + (((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k) =
+                        make_float4(acc[m][q][rg * 4 + 0], acc[m][q][rg * 4 + 1], acc[m][q][rg * 4 + 2], acc[m][q][rg * 4 + 3]);
+                } else {
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + k);
+                        bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
                     }
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(acc[m][q][rg * 4 + 0] + bv[0]) | ((unsigned)f2bf(acc[m][q][rg * 4 + 1] + bv[1]) << 16);
+                    pk.y = (unsigned)f2bf(acc[m][q][rg * 4 + 2] + bv[2]) | ((unsigned)f2bf(acc[m][q][rg * 4 + 3] + bv[3]) << 16);
+                    if (k < g.K1)
+                        *reinterpret_cast<uint2 *>(y1 + ov * g.K1 + k) = pk;
+                    else
+                        *reinterpret_cast<uint2 *>(y2 + ov * g.K2 + (k - g.K1)) = pk;
                 }
             }
-        }
+    }
 }
 
 // y[mapped(n,o)][k] = bf16( bias[k] + sum_s part[s][n][o][k] )
@@ -306,6 +313,228 @@ static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ persistent kernel
+// 3x3x3 stride-1 layers with 32 reduce and 32 produce channels at high resolution (enc0.conv1, dec5.conv1 and their
+// input gradients: 537 MB of activations, 232 GFLOP each).  A 256-voxel tile is only 108 bf16 MFMAs per wave (3.5k
+// cycles) -- less than one L2 round trip -- so the one-tile-per-workgroup kernel above spends its time waiting for the
+// halo.  Here one workgroup per CU walks its XCD's tiles; all 27 taps' weights (55 KB) stay in LDS for the whole walk,
+// the halo of tile t+1 is fetched into registers while tile t's MFMAs run and lands in the other of two LDS halo buffers
+// (one barrier per tile); B fragments are kept in registers for a filter plane (9 taps x 2 k-steps) so the LDS feeds one
+// A fragment per MFMA.
+constexpr int P_XR = 10;      // uint4 per thread: 600 slots x 4 / 256
+constexpr int P_XS = 80;      // bytes per halo slot (64 + 16 pad)
+constexpr int P_HALO = 600 * P_XS;
+constexpr int P_WB = 27 * 2 * 2 * 32 * 16;  // bytes of the resident weights
+
+__global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
+                                                   const unsigned short *__restrict__ w, const float *__restrict__ bias,
+                                                   unsigned short *__restrict__ y1, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    unsigned char *Wsm = lds8;                 // [tap][s][h][k][16 B]
+    unsigned char *Xs0 = lds8 + P_WB;          // two halo buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3;
+    const int EHW = tg.EH * tg.EW;
+    const int nx = tg.nslots * 4;
+
+    // resident weights: 27 taps x 128 fragments of 16 B, in tap order (the tap -> weight index map is g.wt)
+    for (int f = tid; f < 27 * 128; f += 256) {
+        const int t = f >> 7, r = f & 127;  // r = (s*2 + hh)*32 + k
+        *reinterpret_cast<uint4 *>(Wsm + (size_t)f * 16) =
+            *reinterpret_cast<const uint4 *>(w + ((size_t)g.wt[t] * 128 + r) * 8);
+    }
+    // tile-independent decode of this thread's staging slots
+    int rel[P_XR], cz[P_XR];
+#pragma unroll
+    for (int u = 0; u < P_XR; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx >> 2;
+        const int ez = slot / EHW, rem = slot - ez * EHW;
+        const int ey = rem / tg.EW, ex = rem - ey * tg.EW;
+        rel[u] = ((ez * g.Hi + ey) * g.Wi + ex) * 32 + (idx & 3) * 8;
+        cz[u] = idx < nx ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+    uint4 v[P_XR];
+    int n_, od0, oh0, ow0;
+    auto decode = [&](int it) {
+        unsigned r_ = (unsigned)(xcd * per_xcd + it);
+        ow0 = (int)(r_ % (unsigned)tg.ntw) * 8; r_ /= (unsigned)tg.ntw;
+        oh0 = (int)(r_ % (unsigned)tg.nth) * 8; r_ /= (unsigned)tg.nth;
+        od0 = (int)(r_ % (unsigned)tg.ntd) * 4;
+        n_ = (int)(r_ / (unsigned)tg.ntd);
+    };
+    auto valid = [&](int it) { return it < per_xcd && xcd * per_xcd + it < tg.nitems; };
+    auto load_halo = [&]() {  // of the tile in (n_, od0, oh0, ow0)
+        const int z0 = od0 - 1, y0 = oh0 - 1, x0 = ow0 - 1;
+        const unsigned short *base = a1 + ((((long)n_ * g.Di + z0) * g.Hi + y0) * g.Wi + x0) * 32L;
+#pragma unroll
+        for (int u = 0; u < P_XR; u++) {
+            const int id = z0 + (cz[u] >> 16), ih = y0 + ((cz[u] >> 8) & 255), iw = x0 + (cz[u] & 255);
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (cz[u] >= 0 && !(dbg & 1) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                v[u] = *reinterpret_cast<const uint4 *>(base + rel[u]);
+        }
+    };
+    auto store_halo = [&](unsigned char *Xs) {
+#pragma unroll
+        for (int u = 0; u < P_XR; u++) {
+            const int idx = u * 256 + tid;
+            if (idx < nx) *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * P_XS + (idx & 3) * 16) = v[u];
+        }
+    };
+    int sbase[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) sbase[m] = ((wave * tg.EH + 4 * m + (i >> 3)) * tg.EW + (i & 7)) * P_XS + h * 16;
+    const unsigned char *wl = Wsm + ((size_t)h * 32 + i) * 16;  // + ((t*2 + s)*2)*32*16 = (t*2 + s) * 1024
+
+    int it = local;
+    if (!valid(it)) return;  // whole workgroup
+    decode(it);
+    load_halo();
+    store_halo(Xs0);
+    __syncthreads();  // weights + first halo visible
+    int cur = 0;
+    while (true) {
+        const int itn = it + nlocal;
+        const bool more = valid(itn);  // block-uniform
+        const int cn = n_, cod0 = od0, coh0 = oh0, cow0 = ow0;
+        if (more) {
+            decode(itn);
+            load_halo();  // in flight during this tile's MFMAs
+        }
+        const unsigned char *Xs = Xs0 + (size_t)cur * P_HALO;
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+#pragma unroll 1
+        for (int gz = 0; gz < ((dbg & 2) ? 0 : 3); gz++) {
+            bf16x8 bw[9][2];  // this filter plane's B fragments
+#pragma unroll
+            for (int t9 = 0; t9 < 9; t9++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    uint4 q = *reinterpret_cast<const uint4 *>(wl + (size_t)((gz * 9 + t9) * 2 + s2) * 1024);
+                    bw[t9][s2] = *reinterpret_cast<bf16x8 *>(&q);
+                }
+            bf16x8 af[2][2][2];  // [buffer][m][k-step]
+            auto read_a = [&](int t9, int buf) {
+                const int to = tg.toff[gz * 9 + t9] * P_XS;
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        uint4 q = *reinterpret_cast<const uint4 *>(Xs + sbase[m] + to + s2 * 32);
+                        af[buf][m][s2] = *reinterpret_cast<bf16x8 *>(&q);
+                    }
+            };
+            read_a(0, 0);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; t9++) {
+                if (t9 + 1 < 9) read_a(t9 + 1, (t9 + 1) & 1);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+                        // operands swapped (D^T = W^T X^T): a lane ends up with 4 x 4 CONSECUTIVE output channels of one
+                        // voxel, i.e. 8-byte bf16 stores instead of sixteen 2-byte ones (the 2-byte stores cost more than
+                        // the tile's MFMAs)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[t9][s2], af[t9 & 1][m][s2], acc[m], 0, 0, 0);
+            }
+        }
+        // epilogue of the current tile: D^T layout -- column (lane & 31) = voxel of the M tile, rows = output channels
+        // (r & 3) + 8 * (r >> 2) + 4 * h
+        const int od = cod0 + wave;
+        if (od < g.Do && !(dbg & 4)) {
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int oh = coh0 + 4 * m + (i >> 3), ow = cow0 + (i & 7);
+                if (oh < g.Ho && ow < g.Wo) {
+                    unsigned short *yo = y1 + ((((size_t)cn * g.Dy + od) * g.Hy + oh) * g.Wy + ow) * 32 + 4 * h;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const int k = 8 * rg + 4 * h;
+                        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (bias) {
+                            const float4 b4 = *reinterpret_cast<const float4 *>(bias + k);
+                            bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+                        }
+                        uint2 q;
+                        q.x = (unsigned)f2bf(acc[m][rg * 4 + 0] + bv[0]) | ((unsigned)f2bf(acc[m][rg * 4 + 1] + bv[1]) << 16);
+                        q.y = (unsigned)f2bf(acc[m][rg * 4 + 2] + bv[2]) | ((unsigned)f2bf(acc[m][rg * 4 + 3] + bv[3]) << 16);
+                        *reinterpret_cast<uint2 *>(yo + 8 * rg) = q;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        store_halo(Xs0 + (size_t)(cur ^ 1) * P_HALO);  // the other buffer: nobody reads it during this tile
+        __syncthreads();
+        cur ^= 1;
+        it = itn;
+    }
+}
+
+static int num_cus16() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t p;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// -1: not this kernel's shape
+static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsigned short *w, const float *bias,
+                         unsigned short *y1, hipStream_t s) {
+    static const int off = getenv("MVD_FWD16P") ? (atoi(getenv("MVD_FWD16P")) == 0) : 0;
+    if (off) return -1;
+    if (g.C1 != 32 || g.C2 != 0 || g.K1 != 32 || g.K2 != 0 || g.ntaps != 27 || g.T != 27) return -1;
+    for (int a = 0; a < 3; a++)
+        if (g.sa[a] != 1 || g.so[a] != 1 || g.oo[a] != 0) return -1;
+    if (g.Dy != g.Do || g.Hy != g.Ho || g.Wy != g.Wo) return -1;
+    int mn[3] = {127, 127, 127}, mx[3] = {-127, -127, -127};
+    for (int t = 0; t < 27; t++)
+        for (int a = 0; a < 3; a++) {
+            if (g.off[t][a] < mn[a]) mn[a] = g.off[t][a];
+            if (g.off[t][a] > mx[a]) mx[a] = g.off[t][a];
+        }
+    for (int a = 0; a < 3; a++)
+        if (mn[a] != -1 || mx[a] != 1) return -1;
+    Fwd16Tile tg;
+    memset(&tg, 0, sizeof(tg));
+    tg.EH = 10; tg.EW = 10; tg.nslots = 600;
+    for (int t = 0; t < 27; t++)
+        tg.toff[t] = ((g.off[t][0] + 1) * tg.EH + (g.off[t][1] + 1)) * tg.EW + (g.off[t][2] + 1);
+    tg.ntd = (g.Do + 3) / 4;
+    tg.nth = (g.Ho + 7) / 8;
+    tg.ntw = (g.Wo + 7) / 8;
+    const long nitems = (long)g.N * tg.ntd * tg.nth * tg.ntw;
+    const long ncu = ((long)num_cus16() / 8) * 8;
+    if (nitems < 4 * ncu || nitems > (1L << 30)) return -1;  // a walk of >= 4 tiles per workgroup or it does not pay
+    if ((long)g.N * g.Di * g.Hi * g.Wi * 32 >= (1L << 31)) return -1;  // 32-bit element offsets inside a tile
+    tg.nitems = (int)nitems;
+    const size_t lds = (size_t)P_WB + 2 * (size_t)P_HALO;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd16p), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)LDS_LIMIT16) != hipSuccess) {
+            set_error("conv fwd16p: cannot raise the dynamic LDS limit");
+            return 1;
+        }
+        configured = true;
+    }
+    static const int dbg = getenv("MVD_FWD16P_DBG") ? atoi(getenv("MVD_FWD16P_DBG")) : 0;
+    hipLaunchKernelGGL(k_fwd16p, dim3((unsigned)ncu), dim3(256), lds, s, g, tg, a1, w, bias, y1, dbg);
+    return check_launch("conv fwd16p (persistent bf16 mfma)");
+}
+
 // returns 0 ok, >0 error, -1 unsupported shape
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
              const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s) {
@@ -320,6 +549,10 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
             if (g.off[t][a] < mn[a]) mn[a] = g.off[t][a];
             if (g.off[t][a] > mx[a]) mx[a] = g.off[t][a];
         }
+    {
+        int r = launch_fwd16p(g, a1, w, bias, y1, s);
+        if (r >= 0) return r;
+    }
     const int NT = (K % 64 == 0) ? 2 : 1;
     auto magic = [](int d, int nmax) -> int {
         int m = (1 << 20) / d + 1;  // 20-bit reciprocal: n < 2048 keeps n*m inside int32

@@ -39,6 +39,7 @@ def close_bf16(a, ref, what):
     (32, 0, 64, (16, 12, 20), 2, 1),
     (320, 320, 320, (4, 4, 4), 1, 2),
     (128, 0, 128, (6, 7, 8), (1, 2, 2), 1),
+    (32, 0, 32, (38, 70, 60), 1, 2),     # >= 4 tiles per CU: the persistent weights-resident kernel, ragged tiles
 ])
 def test_conv3d_bf16_fwd_dgrad(C1, C2, K, sp, stride, N):
     from multimodal_mvd_seg_amd._lib import call, i3, query
