@@ -259,30 +259,34 @@ __global__ __launch_bounds__(256, 4) void k_convT_fwd16(const TranspGeom g, cons
                 for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                     for (int j = 0; j < 2; j++)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][s2], b[u][j][s2], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[u][j][s2], a[u][s2], acc[j], 0, 0, 0);  // D^T: see epilogue
             }
         }
     }
-    const int k = kb * 32 + i;
-    const float bv = bias ? bias[k] : 0.f;
+    // D^T layout (operands swapped): column (lane & 31) = this lane's own voxel, rows = output channels
+    // (r & 3) + 8 * (r >> 2) + 4 * h: four 8-byte packets of 4 consecutive channels per position
     const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
-    const int ob_own = (int)out_base(g, (unsigned)v);
-    int poff[2];
+    if (vb + i < g.NV) {
+        const long ob = out_base(g, (unsigned)v);
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int p = p0 + (j < np ? j : 0);
-        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
-        poff[j] = (pd * Hy + ph) * Wy + pw;
-    }
+        for (int j = 0; j < 2; j++)
+            if (j < np) {
+                const int p = p0 + j;
+                const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+                unsigned short *yo = y + (size_t)(ob + ((long)pd * Hy + ph) * Wy + pw) * g.K + kb * 32 + 4 * h;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int ob = __shfl(ob_own, row, 64);
-        if (vb + row < g.NV) {
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-                if (j < np) y[(size_t)(ob + poff[j]) * g.K + k] = f2bf(acc[j][r] + bv);
-        }
+                for (int rg = 0; rg < 4; rg++) {
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + kb * 32 + 8 * rg + 4 * h);
+                        bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+                    }
+                    uint2 q;
+                    q.x = (unsigned)f2bf(acc[j][rg * 4 + 0] + bv[0]) | ((unsigned)f2bf(acc[j][rg * 4 + 1] + bv[1]) << 16);
+                    q.y = (unsigned)f2bf(acc[j][rg * 4 + 2] + bv[2]) | ((unsigned)f2bf(acc[j][rg * 4 + 3] + bv[3]) << 16);
+                    *reinterpret_cast<uint2 *>(yo + 8 * rg) = q;
+                }
+            }
     }
 }
 
@@ -333,20 +337,25 @@ __global__ __launch_bounds__(256, 4) void k_convT_dgrad16(const TranspGeom g, co
                 for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                     for (int q = 0; q < NT; q++)
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][s2], b[u][q][s2], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[u][q][s2], a[u][s2], acc[q], 0, 0, 0);  // D^T
             }
         }
     }
+    // D^T layout: column = this lane's own voxel, rows = input channels (r & 3) + 8 * (r >> 2) + 4 * h
+    if (vb + i < g.NV) {
 #pragma unroll
-    for (int q = 0; q < NT; q++)
-        if (cb0 + q < ncb) {
-            const int c = (cb0 + q) * 32 + i;
+        for (int q = 0; q < NT; q++)
+            if (cb0 + q < ncb) {
+                unsigned short *xo = dx + (size_t)v * g.C + (cb0 + q) * 32 + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (vb + row < g.NV) dx[(size_t)(vb + row) * g.C + c] = f2bf(acc[q][r]);
+                for (int rg = 0; rg < 4; rg++) {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(acc[q][rg * 4 + 0]) | ((unsigned)f2bf(acc[q][rg * 4 + 1]) << 16);
+                    pk.y = (unsigned)f2bf(acc[q][rg * 4 + 2]) | ((unsigned)f2bf(acc[q][rg * 4 + 3]) << 16);
+                    *reinterpret_cast<uint2 *>(xo + 8 * rg) = pk;
+                }
             }
-        }
+    }
 }
 
 static bool transp_geom(TranspGeom &g, int N, int D, int H, int W, int C, int K, const int st[3]) {
