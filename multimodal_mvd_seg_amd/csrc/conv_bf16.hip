@@ -321,12 +321,13 @@ static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a
 // the halo of tile t+1 is fetched into registers while tile t's MFMAs run and lands in the other of two LDS halo buffers
 // (one barrier per tile); B fragments are kept in registers for a filter plane (9 taps x 2 k-steps) so the LDS feeds one
 // A fragment per MFMA.
-constexpr int P_XR = 10;      // uint4 per thread: 600 slots x 4 / 256
+constexpr int P_TPB = 512;    // 8 waves: d-plane = wave & 3, row block (4 rows) = wave >> 2; two waves per SIMD
+constexpr int P_XR = 5;       // uint4 per thread: 600 slots x 4 / 512
 constexpr int P_XS = 80;      // bytes per halo slot (64 + 16 pad)
 constexpr int P_HALO = 600 * P_XS;
 constexpr int P_WB = 27 * 2 * 2 * 32 * 16;  // bytes of the resident weights
 
-__global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
+__global__ __launch_bounds__(512, 2) void k_fwd16p(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
                                                    const unsigned short *__restrict__ w, const float *__restrict__ bias,
                                                    unsigned short *__restrict__ y1, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16T
     const int nx = tg.nslots * 4;
 
     // resident weights: 27 taps x 128 fragments of 16 B, in tap order (the tap -> weight index map is g.wt)
-    for (int f = tid; f < 27 * 128; f += 256) {
+    for (int f = tid; f < 27 * 128; f += P_TPB) {
         const int t = f >> 7, r = f & 127;  // r = (s*2 + hh)*32 + k
         *reinterpret_cast<uint4 *>(Wsm + (size_t)f * 16) =
             *reinterpret_cast<const uint4 *>(w + ((size_t)g.wt[t] * 128 + r) * 8);
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16T
     int rel[P_XR], cz[P_XR];
 #pragma unroll
     for (int u = 0; u < P_XR; u++) {
-        const int idx = u * 256 + tid;
+        const int idx = u * P_TPB + tid;
         const int slot = idx >> 2;
         const int ez = slot / EHW, rem = slot - ez * EHW;
         const int ey = rem / tg.EW, ex = rem - ey * tg.EW;
@@ -381,13 +382,12 @@ __global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16T
     auto store_halo = [&](unsigned char *Xs) {
 #pragma unroll
         for (int u = 0; u < P_XR; u++) {
-            const int idx = u * 256 + tid;
+            const int idx = u * P_TPB + tid;
             if (idx < nx) *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * P_XS + (idx & 3) * 16) = v[u];
         }
     };
-    int sbase[2];
-#pragma unroll
-    for (int m = 0; m < 2; m++) sbase[m] = ((wave * tg.EH + 4 * m + (i >> 3)) * tg.EW + (i & 7)) * P_XS + h * 16;
+    const int wd = wave & 3, wm = wave >> 2;
+    const int sbase = ((wd * tg.EH + 4 * wm + (i >> 3)) * tg.EW + (i & 7)) * P_XS + h * 16;
     const unsigned char *wl = Wsm + ((size_t)h * 32 + i) * 16;  // + ((t*2 + s)*2)*32*16 = (t*2 + s) * 1024
 
     int it = local;
@@ -406,11 +406,9 @@ __global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16T
             load_halo();  // in flight during this tile's MFMAs
         }
         const unsigned char *Xs = Xs0 + (size_t)cur * P_HALO;
-        f32x16 acc[2];
+        f32x16 acc;
 #pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll 1
         for (int gz = 0; gz < ((dbg & 2) ? 0 : 3); gz++) {
             bf16x8 bw[9][2];  // this filter plane's B fragments
@@ -421,16 +419,14 @@ __global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16T
                     uint4 q = *reinterpret_cast<const uint4 *>(wl + (size_t)((gz * 9 + t9) * 2 + s2) * 1024);
                     bw[t9][s2] = *reinterpret_cast<bf16x8 *>(&q);
                 }
-            bf16x8 af[2][2][2];  // [buffer][m][k-step]
+            bf16x8 af[2][2];  // [buffer][k-step]
             auto read_a = [&](int t9, int buf) {
                 const int to = tg.toff[gz * 9 + t9] * P_XS;
 #pragma unroll
-                for (int m = 0; m < 2; m++)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; s2++) {
-                        uint4 q = *reinterpret_cast<const uint4 *>(Xs + sbase[m] + to + s2 * 32);
-                        af[buf][m][s2] = *reinterpret_cast<bf16x8 *>(&q);
-                    }
+                for (int s2 = 0; s2 < 2; s2++) {
+                    uint4 q = *reinterpret_cast<const uint4 *>(Xs + sbase + to + s2 * 32);
+                    af[buf][s2] = *reinterpret_cast<bf16x8 *>(&q);
+                }
             };
             read_a(0, 0);
 #pragma unroll
@@ -438,21 +434,18 @@ __global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16T
                 if (t9 + 1 < 9) read_a(t9 + 1, (t9 + 1) & 1);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-                    for (int m = 0; m < 2; m++)
                         // operands swapped (D^T = W^T X^T): a lane ends up with 4 x 4 CONSECUTIVE output channels of one
                         // voxel, i.e. 8-byte bf16 stores instead of sixteen 2-byte ones (the 2-byte stores cost more than
                         // the tile's MFMAs)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[t9][s2], af[t9 & 1][m][s2], acc[m], 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw[t9][s2], af[t9 & 1][s2], acc, 0, 0, 0);
             }
         }
         // epilogue of the current tile: D^T layout -- column (lane & 31) = voxel of the M tile, rows = output channels
         // (r & 3) + 8 * (r >> 2) + 4 * h
-        const int od = cod0 + wave;
+        const int od = cod0 + wd;
         if (od < g.Do && !(dbg & 4)) {
-#pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const int oh = coh0 + 4 * m + (i >> 3), ow = cow0 + (i & 7);
+            {
+                const int oh = coh0 + 4 * wm + (i >> 3), ow = cow0 + (i & 7);
                 if (oh < g.Ho && ow < g.Wo) {
                     unsigned short *yo = y1 + ((((size_t)cn * g.Dy + od) * g.Hy + oh) * g.Wy + ow) * 32 + 4 * h;
 #pragma unroll
@@ -464,8 +457,8 @@ __global__ __launch_bounds__(256, 1) void k_fwd16p(const FwdGeom g, const Fwd16T
                             bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
                         }
                         uint2 q;
-                        q.x = (unsigned)f2bf(acc[m][rg * 4 + 0] + bv[0]) | ((unsigned)f2bf(acc[m][rg * 4 + 1] + bv[1]) << 16);
-                        q.y = (unsigned)f2bf(acc[m][rg * 4 + 2] + bv[2]) | ((unsigned)f2bf(acc[m][rg * 4 + 3] + bv[3]) << 16);
+                        q.x = (unsigned)f2bf(acc[rg * 4 + 0] + bv[0]) | ((unsigned)f2bf(acc[rg * 4 + 1] + bv[1]) << 16);
+                        q.y = (unsigned)f2bf(acc[rg * 4 + 2] + bv[2]) | ((unsigned)f2bf(acc[rg * 4 + 3] + bv[3]) << 16);
                         *reinterpret_cast<uint2 *>(yo + 8 * rg) = q;
                     }
                 }
@@ -531,7 +524,7 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
         configured = true;
     }
     static const int dbg = getenv("MVD_FWD16P_DBG") ? atoi(getenv("MVD_FWD16P_DBG")) : 0;
-    hipLaunchKernelGGL(k_fwd16p, dim3((unsigned)ncu), dim3(256), lds, s, g, tg, a1, w, bias, y1, dbg);
+    hipLaunchKernelGGL(k_fwd16p, dim3((unsigned)ncu), dim3(P_TPB), lds, s, g, tg, a1, w, bias, y1, dbg);
     return check_launch("conv fwd16p (persistent bf16 mfma)");
 }
 
