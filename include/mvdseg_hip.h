@@ -283,6 +283,17 @@ int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *
 int mvd_ndhwc_to_nchw(const float *src, float *dst, int N, int C, long V, void *stream);
 int mvd_axpy(float *y, const float *x, float a, long n, void *stream); /* y += a*x */
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Sliding-window inference helpers.  Planar fp32 [C][D][H][W].
+ * mvd_flip_add: dst (+)= flip(src) on the axes of mask (bit 0: D, 1: H, 2: W) -- the mirror test-time augmentation of
+ *   predict_from_raw_data.py:562-588 (torch.flip of the input and of each prediction, summed);
+ * mvd_sw_accumulate: logits[:, tile] += tile_logits * scale * gauss, npred[tile] += gauss (gauss NULL: weight 1)
+ *   -- predict_from_raw_data.py:706-707;  mvd_sw_normalize: logits /= npred (:709). */
+int mvd_flip_add(const float *src, float *dst, int C, int D, int H, int W, int mask, int accumulate, void *stream);
+int mvd_sw_accumulate(const float *tile, const float *gauss, float scale, float *logits, float *npred, int K, int pd, int ph,
+                      int pw, int D, int H, int W, int oz, int oy, int ox, void *stream);
+int mvd_sw_normalize(float *logits, const float *npred, int K, long V, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,10 @@ SIGNATURES = {
     "mvd_nchw_to_ndhwc": (c_int, [_P, _P, c_int, c_int, c_long, _P]),
     "mvd_ndhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_long, _P]),
     "mvd_axpy": (c_int, [_P, _P, c_float, c_long, _P]),
+    "mvd_flip_add": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "mvd_sw_accumulate": (c_int, [_P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, _P]),
+    "mvd_sw_normalize": (c_int, [_P, _P, c_int, c_long, _P]),
 }
 
 _lib = None

@@ -583,3 +583,55 @@ def test_cfg2_network_gradients_vs_fp64_truth():
         e_cpu = float((g32[n].grad.double() - r).norm()) / nr
         # both errors are round-off of two fp32 evaluation orders (random variables of the same scale)
         assert e_hip <= 5 * e_cpu + 5e-4, f"{n}: relL2 hip {e_hip:.2e} vs torch-fp32 {e_cpu:.2e}"
+
+
+# ================================================================================================ inference (8f-1)
+@pytest.mark.parametrize("mask", [1, 2, 4, 3, 5, 6, 7])
+def test_flip_add_kernel_equals_torch_flip(mask):
+    from multimodal_mvd_seg_amd._lib import call
+    import ctypes
+    g = torch.Generator().manual_seed(mask)
+    x = torch.randn(3, 5, 6, 7, generator=g)
+    y = torch.randn(3, 5, 6, 7, generator=g)
+    dims = tuple(a + 1 for a in range(3) if mask & (1 << a))
+    xd, yd = x.to(DEV), y.to(DEV)
+    out = torch.empty_like(xd)
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    call("mvd_flip_add", P(xd), P(out), 3, 5, 6, 7, mask, 0, s)
+    assert torch.equal(out.cpu(), torch.flip(x, dims))
+    call("mvd_flip_add", P(xd), P(yd), 3, 5, 6, 7, mask, 1, s)
+    assert torch.equal(yd.cpu(), y + torch.flip(x, dims))
+
+
+@pytest.mark.parametrize("mirror,gauss", [((0, 1, 2), True), ((), True), ((1, 2), False)])
+def test_sliding_window_prediction_vs_oracle(mirror, gauss):
+    """SlidingWindowPredictor against the CPU restatement of predict_sliding_window_return_logits, both driving the SAME
+    HIP network (the tile logits are identical; what is compared is padding, step placement, mirror TTA, Gaussian
+    blending and normalisation).  Image smaller than the patch on one axis (padding path), several tiles on the others."""
+    from torch import nn
+    from multimodal_mvd_seg_amd.inference import SlidingWindowPredictor
+    from multimodal_mvd_seg_amd.network import MI355PlainConvUNet, InitWeights_He
+    from oracle import infer_oracle as IO
+    torch.manual_seed(3)
+    net = MI355PlainConvUNet(4, 3, [32, 64, 128], nn.Conv3d, 3, [[1, 1, 1], [2, 2, 2], [2, 2, 2]], 2, 5, 2, True,
+                             nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, None, None, nn.LeakyReLU,
+                             {'inplace': True}, deep_supervision=True).to(DEV)
+    net.apply(InitWeights_He(1e-2))
+    patch = (32, 32, 32)
+    img = torch.randn(4, 28, 44, 50, generator=torch.Generator().manual_seed(5))
+    pred = SlidingWindowPredictor(net, patch, 5, 0.5, gauss, len(mirror) > 0, mirror, DEV)
+    out = pred.predict_sliding_window_return_logits(img)
+    assert tuple(out.shape) == (5, 28, 44, 50)
+    assert net.decoder.deep_supervision is True  # restored
+
+    def oracle_net(x):
+        net.eval()
+        net.decoder.deep_supervision = False
+        with torch.no_grad():
+            y = net(x.to(DEV)).cpu()
+        net.decoder.deep_supervision = True
+        return y
+
+    ref = IO.predict_sliding_window_return_logits(oracle_net, img, patch, 5, 0.5, gauss, mirror if mirror else None)
+    close(out, ref, 2e-5, 1e-5, "sliding-window logits")

@@ -229,3 +229,24 @@ def test_ref_extension_if_built():
     dgm = m.persistenceForwardHom(s, 0, 0)[0].detach().numpy()
     b, de, _ = cc_oracle.h0_persistence(f, 6)
     assert np.array_equal(dgm[np.lexsort((dgm[:, 1], dgm[:, 0]))], _sorted_pairs(b, de))
+
+
+def test_sliding_window_steps_known_answer_and_gaussian_map():
+    """sliding_window_prediction.py:37-38 states the expected placement for (image 110, patch 64, step 0.5); the host
+    Gaussian map (numpy, separable) must equal the scipy.ndimage.gaussian_filter construction the reference uses."""
+    import importlib.util
+    from oracle import infer_oracle as IO
+    assert IO.compute_steps_for_sliding_window((110,), (64,), 0.5) == [[0, 23, 46]]
+    assert IO.compute_steps_for_sliding_window((64, 70, 128), (64, 64, 64), 0.5) == [[0], [0, 6], [0, 32, 64]]
+    src = open(os.path.join(os.path.dirname(__file__), "..", "multimodal_mvd_seg_amd", "inference.py")).read()
+    ns = {}
+    exec(compile(src.replace("from ._lib import call", "call = None"), "inference.py", "exec"), ns)  # host logic only
+    for ts in [(8, 8, 8), (16, 12, 20), (5, 7, 9), (64, 64, 64)]:
+        a = ns["compute_gaussian"](ts, 1. / 8, 1000.0)
+        b = IO.compute_gaussian(ts, 1. / 8, 1000.0).numpy()
+        assert np.abs(a - b).max() <= 1e-6 * b.max(), ts
+        assert ns["compute_steps_for_sliding_window"](ts, tuple(max(2, t // 2) for t in ts), 0.5) == \
+            IO.compute_steps_for_sliding_window(ts, tuple(max(2, t // 2) for t in ts), 0.5)
+    img = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    padded, revert = IO.pad_to_patch(img, (8, 4, 7))
+    assert tuple(padded.shape) == (2, 8, 4, 7) and torch.equal(padded[revert], img)
