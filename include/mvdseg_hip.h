@@ -267,6 +267,21 @@ int mvd_cc_label(const uint8_t *mask, int32_t *labels, int32_t *count, int D, in
 /* mask[v] = (f[v] > thr) (or >= when ge != 0) */
 int mvd_threshold_mask(const float *f, uint8_t *mask, long n, float thr, int ge, void *stream);
 
+/* Connected-component post-processing of a predicted segmentation.  Replaces, on device,
+ * remove_all_but_largest_component_from_segmentation (nnunetv2/postprocessing/remove_connected_components.py:22-34):
+ *   mask = union over label_set of (seg == l)            -> mvd_seg_label_mask  (region_or_label_to_mask, :27-30)
+ *   cc   = mvd_cc_label(mask, conn = 26)                  (skimage.measure.label full connectivity inside acvl_utils)
+ *   kept = the `keep` (1 or 2) largest components         -> mvd_cc_keep_largest (remove_all_but_two_largest_component, :31)
+ *   out  = seg, with mask & ~kept set to background       -> mvd_seg_remove_components (:32-33)
+ * All integer; bit-exact against oracle/postproc_oracle.py.  Ties in component size go to the component with the
+ * smaller canonical label (first in scan order).  label_set is a HOST array of 1..16 labels.  kept: int32[4] on the
+ * device = {label0, label1, size0, size1} (0 = none).  workspace: mvd_cc_keep_workspace_bytes(n) device bytes. */
+int mvd_seg_label_mask(const int32_t *seg, uint8_t *mask, long n, const int32_t *label_set, int nlabels, void *stream);
+size_t mvd_cc_keep_workspace_bytes(long n);
+int mvd_cc_keep_largest(const int32_t *cc_labels, long n, int keep, int32_t *kept, void *workspace, void *stream);
+int mvd_seg_remove_components(const int32_t *seg, const int32_t *cc_labels, const int32_t *kept, int32_t *out, long n,
+                              int background, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * SGD(momentum, nesterov, weight decay) with global-norm clipping (K10).  Replaces
  * torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step (nnUNetTrainer.py:473-477, :918-924) on flat

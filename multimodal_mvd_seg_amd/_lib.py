@@ -100,6 +100,10 @@ SIGNATURES = {
     "mvd_dot_sum_workspace_bytes": (c_size_t, [c_long]),
     "mvd_cc_label": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_threshold_mask": (c_int, [_P, _P, c_long, c_float, c_int, _P]),
+    "mvd_seg_label_mask": (c_int, [_P, _P, c_long, _P, c_int, _P]),
+    "mvd_cc_keep_workspace_bytes": (c_size_t, [c_long]),
+    "mvd_cc_keep_largest": (c_int, [_P, c_long, c_int, _P, _P, _P]),
+    "mvd_seg_remove_components": (c_int, [_P, _P, _P, _P, c_long, c_int, _P]),
     "mvd_sumsq_workspace_bytes": (c_size_t, [c_long]),
     "mvd_grad_sumsq": (c_int, [_P, _P, c_long, _P, c_size_t, _P]),
     "mvd_sgd_nesterov_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, _P]),

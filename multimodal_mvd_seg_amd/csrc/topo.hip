@@ -304,6 +304,110 @@ __global__ void k_cc_finish(int32_t *labels, long n) {
         labels[i] = labels[i] + 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Connected-component post-processing (remove_connected_components.py:22-34): label-set mask, component
+// sizes, the `keep` largest components, relabel of everything else in the mask to the background label.
+struct LabelSet {
+    int n;
+    int32_t v[16];
+};
+
+__global__ void k_seg_label_mask(const int32_t *__restrict__ seg, uint8_t *__restrict__ mask, long n, LabelSet ls) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int32_t s = seg[i];
+        bool in = false;
+        for (int k = 0; k < ls.n; k++) in |= (s == ls.v[k]);
+        mask[i] = in ? 1 : 0;
+    }
+}
+
+// sizes[root] += 1 for every voxel of the component whose canonical label is root + 1.  Each thread walks RUN
+// consecutive voxels and issues one integer atomic per run of equal labels (components are spatially coherent, so
+// a large component does not serialise n atomics on one address).
+template <int RUN>
+__global__ void k_cc_sizes(const int32_t *__restrict__ labels, int32_t *__restrict__ sizes, long n) {
+    long nchunks = (n + RUN - 1) / RUN;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long)gridDim.x * blockDim.x) {
+        long i0 = c * RUN, i1 = i0 + RUN < n ? i0 + RUN : n;
+        int32_t cur = 0, cnt = 0;
+        for (long i = i0; i < i1; i++) {
+            int32_t l = labels[i];
+            if (l != cur) {
+                if (cur > 0) atomicAdd(&sizes[cur - 1], cnt);
+                cur = l;
+                cnt = 0;
+            }
+            cnt++;
+        }
+        if (cur > 0) atomicAdd(&sizes[cur - 1], cnt);
+    }
+}
+
+// key = size << 32 | ~root: larger size wins, ties go to the smaller canonical label.  size 0 == no component.
+__device__ __forceinline__ void top2_push(unsigned long long &a1, unsigned long long &a2, unsigned long long k) {
+    if (k > a1) {
+        a2 = a1;
+        a1 = k;
+    } else if (k > a2) {
+        a2 = k;
+    }
+}
+__device__ __forceinline__ void top2_block(unsigned long long &a1, unsigned long long &a2, unsigned long long *sm) {
+    // sm: 2 * blockDim.x keys
+    const int t = threadIdx.x;
+    sm[2 * t] = a1;
+    sm[2 * t + 1] = a2;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            unsigned long long b1 = sm[2 * (t + s)], b2 = sm[2 * (t + s) + 1];
+            top2_push(a1, a2, b1);
+            top2_push(a1, a2, b2);
+            sm[2 * t] = a1;
+            sm[2 * t + 1] = a2;
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_cc_top2_part(const int32_t *__restrict__ sizes, long n,
+                                                      unsigned long long *__restrict__ cand) {
+    __shared__ unsigned long long sm[512];
+    unsigned long long a1 = 0, a2 = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int32_t sz = sizes[i];
+        if (sz > 0) top2_push(a1, a2, ((unsigned long long)(uint32_t)sz << 32) | (uint32_t)(~(uint32_t)i));
+    }
+    top2_block(a1, a2, sm);
+    if (threadIdx.x == 0) {
+        cand[2 * blockIdx.x] = a1;
+        cand[2 * blockIdx.x + 1] = a2;
+    }
+}
+__global__ void __launch_bounds__(256) k_cc_top2_final(const unsigned long long *__restrict__ cand, int ncand, int keep,
+                                                       int32_t *__restrict__ kept) {
+    __shared__ unsigned long long sm[512];
+    unsigned long long a1 = 0, a2 = 0;
+    for (int i = threadIdx.x; i < ncand; i += blockDim.x) top2_push(a1, a2, cand[i]);
+    top2_block(a1, a2, sm);
+    if (threadIdx.x == 0) {
+        // kept[0..1] = canonical labels (0 = none); kept[2..3] = their sizes
+        kept[0] = (a1 >> 32) ? (int32_t)(~(uint32_t)a1) + 1 : 0;
+        kept[1] = (keep > 1 && (a2 >> 32)) ? (int32_t)(~(uint32_t)a2) + 1 : 0;
+        kept[2] = (int32_t)(a1 >> 32);
+        kept[3] = keep > 1 ? (int32_t)(a2 >> 32) : 0;
+    }
+}
+
+__global__ void k_seg_remove_components(const int32_t *__restrict__ seg, const int32_t *__restrict__ cc,
+                                        const int32_t *__restrict__ kept, int32_t *__restrict__ out, long n,
+                                        int32_t background) {
+    const int32_t k0 = kept[0], k1 = kept[1];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int32_t l = cc[i];
+        out[i] = (l > 0 && l != k0 && l != k1) ? background : seg[i];
+    }
+}
+
 }  // namespace mvd
 
 using namespace mvd;
@@ -436,5 +540,45 @@ int mvd_cc_label(const uint8_t *mask, int32_t *labels, int32_t *count, int D, in
     hipLaunchKernelGGL(k_cc_compress, dim3(ew_grid(n)), dim3(256), 0, s, labels, n);
     hipLaunchKernelGGL(k_cc_finish, dim3(ew_grid(n)), dim3(256), 0, s, labels, n);
     return check_launch("cc_label relabel");
+}
+
+int mvd_seg_label_mask(const int32_t *seg, uint8_t *mask, long n, const int32_t *label_set, int nlabels, void *stream) {
+    MVD_REQUIRE(seg && mask && label_set, "seg_label_mask: null pointer");
+    MVD_REQUIRE(n > 0 && nlabels >= 1 && nlabels <= 16, "seg_label_mask: 1..16 labels");
+    LabelSet ls;
+    ls.n = nlabels;
+    for (int i = 0; i < 16; i++) ls.v[i] = i < nlabels ? label_set[i] : 0;  // host array, passed by value
+    hipLaunchKernelGGL(k_seg_label_mask, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), seg, mask, n, ls);
+    return check_launch("seg_label_mask");
+}
+
+size_t mvd_cc_keep_workspace_bytes(long n) { return (size_t)n * sizeof(int32_t) + 2 * 1024 * sizeof(uint64_t); }
+
+int mvd_cc_keep_largest(const int32_t *cc_labels, long n, int keep, int32_t *kept, void *workspace, void *stream) {
+    MVD_REQUIRE(cc_labels && kept && workspace, "cc_keep_largest: null pointer");
+    MVD_REQUIRE(n > 0 && n < 2147483647L && (keep == 1 || keep == 2), "cc_keep_largest: keep must be 1 or 2");
+    hipStream_t s = as_stream(stream);
+    unsigned long long *cand = (unsigned long long *)workspace;  // 2 * 1024 keys, then n sizes
+    int32_t *sizes = (int32_t *)(cand + 2 * 1024);
+    if (hipMemsetAsync(sizes, 0, (size_t)n * sizeof(int32_t), s) != hipSuccess) {
+        set_error("cc_keep_largest: memset failed");
+        return 1;
+    }
+    constexpr int RUN = 16;
+    hipLaunchKernelGGL(k_cc_sizes<RUN>, dim3(ew_grid(cdiv(n, RUN))), dim3(256), 0, s, cc_labels, sizes, n);
+    long nb = cdiv(n, 256);
+    int blocks = (int)(nb > 1024 ? 1024 : nb);
+    hipLaunchKernelGGL(k_cc_top2_part, dim3(blocks), dim3(256), 0, s, sizes, n, cand);
+    hipLaunchKernelGGL(k_cc_top2_final, dim3(1), dim3(256), 0, s, cand, 2 * blocks, keep, kept);
+    return check_launch("cc_keep_largest");
+}
+
+int mvd_seg_remove_components(const int32_t *seg, const int32_t *cc_labels, const int32_t *kept, int32_t *out, long n,
+                              int background, void *stream) {
+    MVD_REQUIRE(seg && cc_labels && kept && out, "seg_remove_components: null pointer");
+    MVD_REQUIRE(n > 0, "seg_remove_components: empty");
+    hipLaunchKernelGGL(k_seg_remove_components, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), seg, cc_labels, kept,
+                       out, n, (int32_t)background);
+    return check_launch("seg_remove_components");
 }
 }

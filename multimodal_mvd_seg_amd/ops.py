@@ -766,6 +766,39 @@ def threshold_mask(f, thr, ge=False):
     return m
 
 
+def seg_label_mask(seg, labels):
+    """uint8 mask of the voxels of an int32 segmentation whose label is in `labels` (1..16 ints)."""
+    _require_cuda(seg)
+    if seg.dtype != torch.int32:
+        raise RuntimeError("seg_label_mask takes an int32 segmentation")
+    x = seg.contiguous()
+    ls = (ctypes.c_int32 * len(labels))(*[int(v) for v in labels])
+    m = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    call("mvd_seg_label_mask", _p(x), _p(m), x.numel(), ctypes.cast(ls, ctypes.c_void_p), len(labels), _stream())
+    return m
+
+
+def cc_keep_largest(cc_labels, keep=2):
+    """int32[4] device tensor {label0, label1, size0, size1} of the `keep` largest components of a canonical
+    label volume (ties -> smaller label)."""
+    _require_cuda(cc_labels)
+    x = cc_labels.contiguous()
+    n = x.numel()
+    ws = torch.empty((query("mvd_cc_keep_workspace_bytes", n),), dtype=torch.uint8, device=x.device)
+    kept = torch.empty((4,), dtype=torch.int32, device=x.device)
+    call("mvd_cc_keep_largest", _p(x), n, int(keep), _p(kept), _p(ws), _stream())
+    return kept
+
+
+def seg_remove_components(seg, cc_labels, kept, background=0):
+    _require_cuda(seg)
+    x = seg.contiguous()
+    out = torch.empty_like(x)
+    call("mvd_seg_remove_components", _p(x), _p(cc_labels.contiguous()), _p(kept), _p(out), x.numel(),
+         int(background), _stream())
+    return out
+
+
 def set_conv_engine(mode):
     """'auto' (MFMA implicit GEMM when the shape allows) or 'scalar' (gather kernels only; cross-check)."""
     call("mvd_set_conv_engine", {"auto": 0, "scalar": 1}[mode])

@@ -635,3 +635,86 @@ def test_sliding_window_prediction_vs_oracle(mirror, gauss):
 
     ref = IO.predict_sliding_window_return_logits(oracle_net, img, patch, 5, 0.5, gauss, mirror if mirror else None)
     close(out, ref, 2e-5, 1e-5, "sliding-window logits")
+
+
+# ------------------------------------------------------------------------------------------ post-processing (8f-3)
+def _pp_seg(rng, shape, thr=0.55):
+    from scipy import ndimage
+    f = ndimage.gaussian_filter(rng.random(shape), 1.5)
+    f = (f - f.min()) / (f.max() - f.min())
+    seg = np.zeros(shape, dtype=np.int32)
+    seg[f > thr] = 1
+    seg[f > thr + 0.12] = 2
+    seg[f < 0.25] = 3
+    return seg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("conn", [6, 26])
+@pytest.mark.parametrize("keep", [1, 2])
+def test_postproc_keep_largest_bit_exact(conn, keep):
+    from multimodal_mvd_seg_amd import postprocessing as PP
+    from oracle import postproc_oracle as PO
+    rng = np.random.default_rng(100 + conn + keep)
+    for shape, thr in (((24, 40, 56), 0.55), ((33, 17, 70), 0.6), ((5, 7, 300), 0.5)):
+        seg = _pp_seg(rng, shape, thr)
+        for labels in (1, [1, 2], [(1, 2), 3], (2, 3)):
+            ref = PO.remove_all_but_largest_component_from_segmentation(seg, labels, 0, keep, conn)
+            got = PP.remove_all_but_largest_component_from_segmentation(seg, labels, 0, num_components=keep,
+                                                                        connectivity=conn)
+            assert got.dtype == seg.dtype and np.array_equal(got, ref), (shape, labels)
+            # idempotent: a second pass changes nothing
+            again = PP.remove_all_but_largest_component_from_segmentation(got, labels, 0, num_components=keep,
+                                                                          connectivity=conn)
+            assert np.array_equal(again, got)
+
+
+@pytest.mark.gpu
+def test_postproc_sizes_ties_and_edge_cases():
+    from multimodal_mvd_seg_amd import ops, postprocessing as PP
+    from oracle import postproc_oracle as PO
+    # kept = {label0, label1, size0, size1}; ties go to the first component in scan order
+    seg = np.zeros((4, 5, 40), dtype=np.int32)
+    seg[0, 0, 0:3] = 1
+    seg[1, 2, 10:13] = 1
+    seg[3, 4, 30:33] = 1
+    seg[3, 0, 0:37] = 1       # 37 voxels: crosses several 16-voxel runs
+    m = ops.seg_label_mask(G(seg), [1])
+    cc, count = ops.cc_label(m, 26)
+    kept = ops.cc_keep_largest(cc, 2).cpu().numpy()
+    assert int(count.item()) == 4
+    assert kept.tolist() == [1 + (3 * 5 + 0) * 40, 1, 37, 3]
+    ref = PO.remove_all_but_largest_component_from_segmentation(seg, 1, 9)
+    got = PP.remove_all_but_largest_component_from_segmentation(seg, 1, background_label=9)
+    assert np.array_equal(got, ref)
+    # empty mask / one component / label not present: no-ops; device tensors stay on the device; input untouched
+    z = torch.zeros((3, 4, 5), dtype=torch.int32, device=DEV)
+    out = PP.remove_all_but_largest_component_from_segmentation(z, 1)
+    assert out.is_cuda and torch.equal(out, z)
+    one = np.ones((3, 4, 5), dtype=np.int64)
+    got = PP.remove_all_but_largest_component_from_segmentation(one, [1], 0)
+    assert got.dtype == np.int64 and np.array_equal(got, one)
+    with pytest.raises(ValueError):
+        PP.remove_all_but_largest_component_from_segmentation(one, list(range(17)))
+    with pytest.raises(RuntimeError):
+        ops.cc_keep_largest(cc, 3)
+
+
+@pytest.mark.gpu
+def test_postproc_full_volume_properties():
+    # full-size predicted volume (192 x 256 x 256): size-independent properties instead of the scipy oracle
+    from multimodal_mvd_seg_amd import ops, postprocessing as PP
+    g = torch.Generator(device="cpu").manual_seed(5)
+    f = torch.rand((1, 1, 48, 64, 64), generator=g)
+    f = torch.nn.functional.interpolate(f, scale_factor=4, mode="trilinear").squeeze().to(DEV)
+    seg = (f > 0.62).to(torch.int32) + (f > 0.7).to(torch.int32)
+    out = PP.remove_all_but_largest_component_from_segmentation(seg, [1, 2], 0)
+    assert torch.equal(out[out != 0], seg[out != 0])            # only removals, never relabels a kept voxel
+    m = ops.seg_label_mask(out, [1, 2])
+    cc, count = ops.cc_label(m, 26)
+    assert int(count.item()) <= 2
+    kept0 = ops.cc_keep_largest(ops.cc_label(ops.seg_label_mask(seg, [1, 2]), 26)[0], 2).cpu()
+    assert int(m.sum().item()) == int(kept0[2] + kept0[3])      # surviving voxels == the two component sizes
+    kept1 = ops.cc_keep_largest(cc, 2).cpu()
+    assert kept1[2:].tolist() == kept0[2:].tolist()
+    assert torch.equal(PP.remove_all_but_largest_component_from_segmentation(out, [1, 2], 0), out)

@@ -250,3 +250,64 @@ def test_sliding_window_steps_known_answer_and_gaussian_map():
     img = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
     padded, revert = IO.pad_to_patch(img, (8, 4, 7))
     assert tuple(padded.shape) == (2, 8, 4, 7) and torch.equal(padded[revert], img)
+
+
+def _blob_seg(rng, shape, thr=0.55):
+    """Smooth random field -> multi-label segmentation with blobs of very different sizes."""
+    from scipy import ndimage
+    f = ndimage.gaussian_filter(rng.random(shape), 1.5)
+    f = (f - f.min()) / (f.max() - f.min())
+    seg = np.zeros(shape, dtype=np.int32)
+    seg[f > thr] = 1
+    seg[f > thr + 0.12] = 2
+    seg[f < 0.25] = 3
+    return seg
+
+
+def test_cc_oracle_partition_matches_scipy_label():
+    # independent pin of oracle/cc_oracle.c: same partition (and component count) as scipy.ndimage.label
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    for conn, rank in ((6, 1), (26, 3)):
+        for p in (0.2, 0.45):
+            m = rng.random((9, 11, 13)) < p
+            labels, n = cc_oracle.cc_label(m, conn)
+            ref, n_ref = ndimage.label(m, structure=ndimage.generate_binary_structure(3, rank))
+            assert n == n_ref
+            # a bijection between the two label sets, foreground only
+            pairs = np.unique(np.stack([labels[m], ref[m]]), axis=1)
+            assert pairs.shape[1] == n and len(set(pairs[0])) == n and len(set(pairs[1])) == n
+            # canonical label = 1 + smallest linear index of the component
+            flat = labels.reshape(-1)
+            for l in np.unique(flat[flat > 0]):
+                assert l == 1 + np.flatnonzero(flat == l)[0]
+
+
+def test_postproc_oracle_known_answer():
+    from oracle import postproc_oracle as PO
+    seg = np.zeros((4, 6, 8), dtype=np.int32)
+    seg[0, 0, 0:5] = 1          # 5 voxels
+    seg[2, 2:4, 2:6] = 2        # 8 voxels (label 2, also in the set)
+    seg[3, 5, 7] = 1            # 1 voxel  -> removed
+    seg[0, 4:6, 6:8] = 1        # 4 voxels -> removed
+    seg[1, 5, 0] = 3            # not in the label set: untouched
+    out = PO.remove_all_but_largest_component_from_segmentation(seg, [1, 2], background_label=0)
+    exp = seg.copy()
+    exp[3, 5, 7] = 0
+    exp[0, 4:6, 6:8] = 0
+    assert np.array_equal(out, exp)
+    out1 = PO.remove_all_but_largest_component_from_segmentation(seg, (1, 2), background_label=7, num_components=1)
+    exp1 = exp.copy()
+    exp1[0, 0, 0:5] = 7
+    exp1[3, 5, 7] = 7
+    exp1[0, 4:6, 6:8] = 7
+    assert np.array_equal(out1, exp1)
+    # diagonal touch joins under 26-connectivity only
+    d = np.zeros((2, 2, 2), dtype=np.int32)
+    d[0, 0, 0] = d[1, 1, 1] = 1
+    m26, s26 = PO.remove_all_but_n_largest_component(d > 0, 1, 26)
+    m6, s6 = PO.remove_all_but_n_largest_component(d > 0, 1, 6)
+    assert s26 == [2] and s6 == [1] and m6[0, 0, 0] and not m6[1, 1, 1]
+    # input is not modified, empty mask is a no-op
+    z = np.zeros((3, 3, 3), dtype=np.int32)
+    assert np.array_equal(PO.remove_all_but_largest_component_from_segmentation(z, 1), z)
