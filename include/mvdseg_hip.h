@@ -309,6 +309,25 @@ int mvd_sw_accumulate(const float *tile, const float *gauss, float scale, float 
                       int pw, int D, int H, int W, int oz, int oy, int ox, void *stream);
 int mvd_sw_normalize(float *logits, const float *npred, int K, long V, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * On-device training feed (the deterministic part).  Replaces, for case volumes resident in HBM, the
+ * crop + constant pad of nnUNetDataLoader3D.generate_train_batch (dataloading/data_loader_3d.py:31-46: data padded
+ * with 0, seg with -1), MirrorTransform (nnUNetTrainer.py:738-739), RemoveLabelTransform(-1, 0) (:745) and
+ * DownsampleSegForDSTransform2 order 0 (deep_supervision_donwsampling.py:27-55) + NumpyToTensor 'float' (:768).
+ * Planar layouts: vol/seg [C][D][H][W] of one case; out [C][pd][ph][pw] float32 (the caller offsets `out` to batch
+ * row j).  (lbz, lby, lbx) = bbox_lbs of get_bbox (base_data_loader.py:56-139; may be negative / overhang).
+ * flip_mask bit 0/1/2 mirrors D/H/W of the padded patch.  Bit-exact against oracle/feed_oracle.py. */
+int mvd_feed_crop_pad_f32(const float *vol, float *out, int C, int D, int H, int W, int pd, int ph, int pw, int lbz,
+                          int lby, int lbx, int flip_mask, float pad, void *stream);
+/* int16 segmentation -> float32 target; after padding with `pad`, voxels equal to replace_from become replace_to
+ * when `replace` != 0 */
+int mvd_feed_crop_pad_seg_i16(const int16_t *seg, float *out, int C, int D, int H, int W, int pd, int ph, int pw, int lbz,
+                              int lby, int lbx, int flip_mask, int pad, int replace, int replace_from, int replace_to,
+                              void *stream);
+/* order-0 resize [BC][D][H][W] -> [BC][d][h][w]: source index floor((2o+1)n/(2m)) per axis (pixel-centre aligned
+ * nearest neighbour == skimage.transform.resize(order=0) == scipy.ndimage.zoom(order=0, grid_mode=True)) */
+int mvd_feed_downsample_seg(const float *in, float *out, long BC, int D, int H, int W, int d, int h, int w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

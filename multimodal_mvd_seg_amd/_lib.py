@@ -114,6 +114,9 @@ SIGNATURES = {
     "mvd_sw_accumulate": (c_int, [_P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, _P]),
     "mvd_sw_normalize": (c_int, [_P, _P, c_int, c_long, _P]),
+    "mvd_feed_crop_pad_f32": (c_int, [_P, _P] + [c_int] * 11 + [c_float, _P]),
+    "mvd_feed_crop_pad_seg_i16": (c_int, [_P, _P] + [c_int] * 15 + [_P]),
+    "mvd_feed_downsample_seg": (c_int, [_P, _P, c_long] + [c_int] * 6 + [_P]),
 }
 
 _lib = None

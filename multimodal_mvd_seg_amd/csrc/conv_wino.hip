@@ -88,6 +88,11 @@ int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStre
 
 constexpr int WXS = 36;   // floats per halo slot (32 + 4 pad)
 constexpr int WXR = 12;   // float4 per thread: 360 slots x 8 / 256 threads = 11.25
+#ifdef MVD_WINO_ABLATE            // ablation build: MVD_WINO_DBG bit 0 skips the halo loads, bit 2 the weight loads
+constexpr bool kAblate = true;
+#else
+constexpr bool kAblate = false;
+#endif
 constexpr int WXB = 6;    // staging batch (loads in flight per thread)
 
 // Workgroup = 4 waves on one 4 x 4 x 8 voxel tile (64 pairs) x 32 output channels.  Wave w: M half = w & 1 (d-planes
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
             for (int q = 0; q < WXB; q++) {
                 const int idx = (base + q) * 256 + tid_;
                 v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nx && !(tg.dbg & 1)) {
+                if (idx < nx && !(kAblate && (tg.dbg & 1))) {
                     const int slot = idx >> 3;
                     const int ez = (slot * tg.magHW) >> 16, rem = slot - ez * EHW;
                     const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
                 // next position's weights: (gi, 1) after (gi, 0), (gi + 1, 0) after (gi, 1); the chunk's last step
                 // re-reads its own block (harmless)
                 const int nxt = pp == 0 ? gi * 4 + 1 : (gi < 8 ? gi * 4 + 4 : gi * 4 + 1);
-                if (!(tg.dbg & 4)) {
+                if (!(kAblate && (tg.dbg & 4))) {
 #pragma unroll
                     for (int e = 0; e < 4; e++)
                         wb[pp ^ 1][e] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + e * uq);
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
                         vv[pp][e] = pp == 0 ? make_float4(s1[e].x - s0[e].x, s1[e].y - s0[e].y, s1[e].z - s0[e].z, s1[e].w - s0[e].w)
                                         : make_float4(s0[e].x - s2[e].x, s0[e].y - s2[e].y, s0[e].z - s2[e].z, s0[e].w - s2[e].w);
                 }
-                if (!(tg.dbg & 2)) {
+                if (!(kAblate && (tg.dbg & 2))) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const float4 bq = wb[pp][e];
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             for (int q = 0; q < 4; q++) {
                 const int idx = (base + q) * 256 + tid_;
                 v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nx && !(tg.dbg & 1)) {
+                if (idx < nx && !(kAblate && (tg.dbg & 1))) {
                     const int slot = idx >> 3;
                     const int ez = (slot * tg.magHW) >> 16, rem = slot - ez * EHW;
                     const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             for (int e = 0; e < 4; e++) {
                 {   // next step's weights: (gz, e + 1), (gz + 1, 0); the chunk's last step re-reads its own
                     const int nxt = (gz == 2 && e == 3) ? gz * 16 + e : (e == 3 ? (gz + 1) * 16 : gz * 16 + e + 1);
-                    if (!(tg.dbg & 4)) {
+                    if (!(kAblate && (tg.dbg & 4))) {
 #pragma unroll
                         for (int b = 0; b < 4; b++)
                             wb[(e + 1) & 1][b] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + b * uq);

@@ -718,3 +718,94 @@ def test_postproc_full_volume_properties():
     kept1 = ops.cc_keep_largest(cc, 2).cpu()
     assert kept1[2:].tolist() == kept0[2:].tolist()
     assert torch.equal(PP.remove_all_but_largest_component_from_segmentation(out, [1, 2], 0), out)
+
+
+# ------------------------------------------------------------------------------------------ device feed (8f-2)
+class _FeedDataset:
+    def __init__(self, shapes, channels, seed):
+        rng = np.random.default_rng(seed)
+        self.cases = {}
+        for i, shp in enumerate(shapes):
+            data = rng.standard_normal((channels, *shp)).astype(np.float32)
+            seg = (rng.random((1, *shp)) > 0.9).astype(np.int16) * rng.integers(1, 5, (1, *shp)).astype(np.int16)
+            seg[0, 0, 0, 0] = -1  # an ignore-style label inside the volume is removed as well
+            self.cases[f"c{i}"] = (data, seg, {"class_locations": {c: np.argwhere(seg == c) for c in (1, 2, 3, 4)}})
+
+    def keys(self):
+        return self.cases.keys()
+
+    def load_case(self, k):
+        return self.cases[k]
+
+
+class _FeedLabels:
+    all_labels = [1, 2, 3, 4]
+    has_ignore_label = False
+
+
+@pytest.mark.gpu
+def test_device_feed_batches_bit_exact_vs_oracle():
+    from multimodal_mvd_seg_amd.dataloading import DeviceDataLoader3D
+    from oracle import feed_oracle as FO
+    ds = _FeedDataset([(40, 44, 52), (17, 60, 30), (33, 20, 70)], 4, 1)
+    cases = {k: (v[0], v[1]) for k, v in ds.cases.items()}
+    for patch, scales in (((32, 32, 32), [1, 0.5, 0.25, 0.125]), ((24, 40, 16), [(1, 1, 1), (1, 0.5, 0.5), (0.5, 0.25, 0.25)])):
+        dl = DeviceDataLoader3D(ds, 6, patch, patch, _FeedLabels(), oversample_foreground_percent=0.33,
+                                mirror_axes=(0, 1, 2), deep_supervision_scales=scales, device=DEV)
+        np.random.seed(11)
+        for _ in range(3):
+            plan = dl.plan_batch()
+            got = dl.generate_train_batch(plan)
+            ref_data, ref_t = FO.generate_train_batch(cases, plan[0], plan[1], plan[2], patch, scales)
+            assert got["data"].dtype == torch.float32 and np.array_equal(got["data"].cpu().numpy(), ref_data)
+            assert len(got["target"]) == len(scales)
+            for g, r in zip(got["target"], ref_t):
+                assert g.dtype == torch.float32 and tuple(g.shape) == r.shape and np.array_equal(g.cpu().numpy(), r)
+                assert float(g.min()) >= 0  # the -1 padding / ignore label never reaches the loss
+    # no deep supervision: a bare tensor
+    dl = DeviceDataLoader3D(ds, 2, (16, 16, 16), (16, 16, 16), _FeedLabels(), device=DEV)
+    b = next(dl)
+    assert torch.is_tensor(b["target"]) and tuple(b["target"].shape) == (2, 1, 16, 16, 16)
+
+
+@pytest.mark.gpu
+def test_device_feed_kernels_edges_and_full_size():
+    from multimodal_mvd_seg_amd import dataloading as DLD
+    from oracle import feed_oracle as FO
+    rng = np.random.default_rng(2)
+    vol = rng.standard_normal((3, 9, 10, 11)).astype(np.float32)
+    seg = rng.integers(-1, 4, (1, 9, 10, 11)).astype(np.int16)
+    gv, gs = G(vol), G(seg)
+    patch = (8, 12, 6)
+    for lbs in ([-3, -1, 7], [5, 4, -5], [-7, 0, 0], [8, 9, 10], [0, -2, 3]):  # overhangs down to a one-voxel overlap
+        for mask in (0, 1, 2, 4, 7):
+            out = torch.empty((3, *patch), dtype=torch.float32, device=DEV)
+            DLD.crop_pad_data(gv, out, lbs, mask, 0.0)
+            assert np.array_equal(out.cpu().numpy(), FO.mirror(FO.crop_pad(vol, lbs, patch, 0), mask))
+            t = torch.empty((1, *patch), dtype=torch.float32, device=DEV)
+            DLD.crop_pad_seg(gs, t, lbs, mask, -1, replace=(-1, 0))
+            assert np.array_equal(t.cpu().numpy(),
+                                  FO.remove_label(FO.mirror(FO.crop_pad(seg, lbs, patch, -1), mask)).astype(np.float32))
+            DLD.crop_pad_seg(gs, t, lbs, mask, -1)  # without RemoveLabel the padding stays -1
+            assert np.array_equal(t.cpu().numpy(), FO.mirror(FO.crop_pad(seg, lbs, patch, -1), mask).astype(np.float32))
+    # a box that misses the volume (get_bbox never produces one; the reference's slicing would mis-shape): all padding
+    out = torch.empty((3, *patch), dtype=torch.float32, device=DEV)
+    DLD.crop_pad_data(gv, out, [-20, 0, 0], 0, 5.0)
+    assert bool((out == 5.0).all())
+    with pytest.raises(RuntimeError):
+        DLD.crop_pad_data(gv, torch.empty((2, *patch), dtype=torch.float32, device=DEV), [0, 0, 0])
+    # BASELINE patch from a full-size case: an in-bounds box is a plain slice, DS targets are strided picks
+    g = torch.Generator(device="cpu").manual_seed(0)
+    big = torch.randn((4, 150, 200, 170), generator=g).to(DEV)
+    bseg = torch.randint(0, 5, (1, 150, 200, 170), generator=g).to(torch.int16).to(DEV)
+    out = torch.empty((4, 128, 128, 128), dtype=torch.float32, device=DEV)
+    DLD.crop_pad_data(big, out, [10, 50, 30])
+    assert torch.equal(out, big[:, 10:138, 50:178, 30:158])
+    t = torch.empty((1, 1, 128, 128, 128), dtype=torch.float32, device=DEV)
+    DLD.crop_pad_seg(bseg, t[0], [10, 50, 30], 0, -1, replace=(-1, 0))
+    assert torch.equal(t[0], bseg[:, 10:138, 50:178, 30:158].float())
+    for k, s in enumerate((0.5, 0.25, 0.125, 0.0625)):
+        f = 2 << k
+        d = DLD.downsample_seg(t, s)
+        assert tuple(d.shape) == (1, 1, 128 // f, 128 // f, 128 // f)
+        assert torch.equal(d, t[:, :, f // 2::f, f // 2::f, f // 2::f])

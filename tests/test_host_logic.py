@@ -174,3 +174,69 @@ def test_flat_params_direct_gradient_sink_semantics():
     assert float(fp.grad.abs().sum()) == 0.0
     assert ps[0]._mvd_take_grad() is not None      # new step
     assert ps[0].grad.data_ptr() == fp.grad.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ device feed: host decisions
+class _ToyDataset:
+    def __init__(self, shapes, seed=0):
+        rng = np.random.default_rng(seed)
+        self.cases = {}
+        for i, shp in enumerate(shapes):
+            data = rng.standard_normal((2, *shp)).astype(np.float32)
+            seg = (rng.random((1, *shp)) > 0.97).astype(np.int16) * rng.integers(1, 3, (1, *shp)).astype(np.int16)
+            locs = {c: np.argwhere(seg == c) for c in (1, 2)}  # rows (0, z, y, x)
+            self.cases[f"case{i}"] = (data, seg, {"class_locations": locs})
+
+    def keys(self):
+        return self.cases.keys()
+
+    def load_case(self, k):
+        return self.cases[k]
+
+
+class _Labels:
+    all_labels = [1, 2]
+    has_ignore_label = False
+
+
+def test_device_loader_bbox_rules_follow_reference():
+    from multimodal_mvd_seg_amd.dataloading import DeviceDataLoader3D
+    ds = _ToyDataset([(20, 24, 28), (9, 30, 12)])
+    patch = (12, 16, 16)
+    dl = DeviceDataLoader3D(ds, 4, patch, patch, _Labels(), oversample_foreground_percent=0.33, mirror_axes=(0, 1, 2),
+                            device="cpu")
+    # oversampling: the last round(B * 0.33)-ish samples are forced foreground (base_data_loader.py:46-50)
+    assert [dl.get_do_oversample(j) for j in range(4)] == [False, False, False, True]
+    np.random.seed(7)
+    for _ in range(50):
+        shape = (20, 24, 28)
+        lbs, ubs = dl.get_bbox(shape, False, None)
+        for i in range(3):
+            assert 0 <= lbs[i] <= shape[i] - patch[i] and ubs[i] - lbs[i] == patch[i]
+    # a volume smaller than the patch along z is padded on both sides: lb in [-(12-9)//2 .. ] (:66-74)
+    seen = set()
+    for _ in range(50):
+        lbs, _ = dl.get_bbox((9, 30, 12), False, None)
+        seen.add(lbs[0])
+        assert -2 <= lbs[0] <= -1 and lbs[2] in (-2,) and 0 <= lbs[1] <= 14
+    assert seen == {-2, -1}
+    # forced foreground: the box contains the selected voxel, clamped at the lower bound only (:131-132)
+    data, seg, props = ds.load_case("case0")
+    for _ in range(50):
+        state = np.random.get_state()
+        lbs, ubs = dl.get_bbox(seg.shape[1:], True, props["class_locations"])
+        np.random.set_state(state)
+        eligible = [c for c in props["class_locations"] if len(props["class_locations"][c]) > 0]
+        cls = eligible[np.random.choice(len(eligible))]
+        vox = props["class_locations"][cls][np.random.choice(len(props["class_locations"][cls]))]
+        assert lbs == [max(0, vox[i + 1] - patch[i] // 2) for i in range(3)]
+    # plan: RNG order keys -> (oversample, bbox) per sample -> mirror draws; reproducible from the seed
+    np.random.seed(3)
+    p1 = dl.plan_batch()
+    np.random.seed(3)
+    p2 = dl.plan_batch()
+    assert p1 == p2 and len(p1[0]) == 4 and all(0 <= f < 8 for f in p1[2])
+    with pytest.raises(RuntimeError):
+        dl.generate_train_batch(p1)  # no CPU path
+    with pytest.raises(NotImplementedError):
+        DeviceDataLoader3D(ds, 2, (16, 20, 20), patch, _Labels(), device="cpu")

@@ -311,3 +311,32 @@ def test_postproc_oracle_known_answer():
     # input is not modified, empty mask is a no-op
     z = np.zeros((3, 3, 3), dtype=np.int32)
     assert np.array_equal(PO.remove_all_but_largest_component_from_segmentation(z, 1), z)
+
+
+def test_feed_oracle_resize_index_and_crop_pad_known_answer():
+    from scipy import ndimage
+    from oracle import feed_oracle as FO
+    # closed-form order-0 index (what the HIP kernel computes) == scipy.ndimage.zoom(grid_mode=True), the call
+    # skimage.transform.resize(order=0) makes
+    for n, m in ((128, 64), (128, 32), (128, 16), (128, 8), (160, 80), (160, 10), (20, 10), (12, 5), (7, 3), (9, 4), (5, 5)):
+        z = ndimage.zoom(np.arange(n, dtype=float), m / n, order=0, mode='nearest', grid_mode=True)
+        assert np.array_equal(z, FO.nn_index(np.arange(m), n, m)), (n, m)
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, 5, (2, 1, 8, 12, 16)).astype(np.float32)
+    for scale in (0.5, 0.25, (1, 0.5, 0.5)):
+        ref = FO.downsample_seg(t, scale)
+        sc = [scale] * 3 if not isinstance(scale, tuple) else scale
+        idx = [FO.nn_index(np.arange(int(round(t.shape[2 + i] * sc[i]))), t.shape[2 + i], int(round(t.shape[2 + i] * sc[i])))
+               for i in range(3)]
+        assert np.array_equal(ref, t[:, :, idx[0]][:, :, :, idx[1]][:, :, :, :, idx[2]])
+    assert FO.downsample_seg(t, 1) is t
+    # crop + pad: a box hanging over the low side of z and the high side of x
+    vol = np.arange(2 * 3 * 4 * 5, dtype=np.float32).reshape(2, 3, 4, 5)
+    out = FO.crop_pad(vol, [-1, 1, 3], (3, 2, 4), 0)
+    assert out.shape == (2, 3, 2, 4)
+    assert np.all(out[:, 0] == 0) and np.all(out[:, :, :, 2:] == 0)
+    assert np.array_equal(out[:, 1:, :, :2], vol[:, 0:2, 1:3, 3:5])
+    seg = np.ones((1, 3, 4, 5), dtype=np.int16)
+    s = FO.crop_pad(seg, [-1, 1, 3], (3, 2, 4), -1)
+    assert s.dtype == np.int16 and (s == -1).sum() == 24 - 2 * 2 * 2 and FO.remove_label(s).min() == 0
+    assert np.array_equal(FO.mirror(vol, 0b101), vol[:, ::-1, :, ::-1])
