@@ -313,6 +313,42 @@ __device__ inline float4 f4_axpy(float s, const float4 b, const float4 a) {  // 
 __device__ inline float4 f4_sub(const float4 a, const float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ inline float4 f4_add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// Packed fp32 VALU through inline asm.  On gfx950 every fp32 VALU instruction takes ~3 cycles away from the fp32 MFMA
+// pipe of its SIMD (tools/probes/valu_mix_probe.hip: they do not overlap, not even across waves), so the input transform
+// is written with v_pk_fma_f32 / v_pk_add_f32 on the register pairs ds_read_b128 delivers -- 16 instead of 32 VALU
+// instructions per 16 MFMAs.  Plain <2 x float> arithmetic does not survive: the backend's pre-emit peephole unpacks
+// packed F32 instructions it finds behind an MFMA.
+// HAZARD: a VALU write needs 2 wait states before an MFMA reads the register as SrcA/B, and the compiler's hazard
+// recognizer does not look inside inline asm -- hence the trailing s_nop 1 of every block whose results feed MFMAs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// One half (two of the four channels of a float4) of the F(2x2,3x3) input transform of a step:
+//   R_c = a_c + sg * b_c (c = 0..3: the four patch columns);  V0 = R0 - R2, V1 = R1 + R2, V2 = R2 - R1, V3 = R1 - R3
+// in place: a0 -> V0, a2 -> V2, a3 -> V3; V1 is returned (a1 is consumed as scratch for R1).
+__device__ __forceinline__ v2f wino2_input_transform(v2f sg, v2f &a0, v2f a1, v2f &a2, v2f &a3, v2f b0, v2f b1, v2f b2,
+                                                     v2f b3) {
+    v2f t;
+    asm("v_pk_fma_f32 %0, %5, %6, %0\n\t"
+        "v_pk_fma_f32 %1, %5, %7, %1\n\t"
+        "v_pk_fma_f32 %2, %5, %8, %2\n\t"
+        "v_pk_fma_f32 %3, %5, %9, %3\n\t"
+        "v_pk_add_f32 %0, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"  // V0 = R0 - R2
+        "v_pk_add_f32 %3, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"  // V3 = R1 - R3
+        "v_pk_add_f32 %4, %1, %2\n\t"                            // V1 = R1 + R2
+        "v_pk_add_f32 %2, %2, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"  // V2 = R2 - R1
+        "s_nop 1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(t)
+        : "v"(sg), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    return t;
+}
+
+#ifndef MVD_W2B
+#define MVD_W2B 12
+#endif
+constexpr int W2B = MVD_W2B;  // staging loads in flight per thread before the LDS stores
+constexpr int W2EH = 6, W2EW = 10, W2EHW = 60;  // halo of the 4 x 4 x 8 tile: 6 x 6 x 10 slots
+
 __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const WinoTile tg, const float *__restrict__ a1,
                                                       const float *__restrict__ a2, const float *__restrict__ u,
                                                       const float *__restrict__ bias, float *__restrict__ y1,
@@ -324,17 +360,17 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     const int per_xcd = (tg.nitems + 7) >> 3;
     const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (item >= tg.nitems) return;  // whole workgroup
+    // the divisions run on the VALU (float reciprocal); readfirstlane moves the wave-uniform results back to scalar
+    // registers so that every address derived from them is scalar arithmetic
     unsigned r_ = (unsigned)item;
-    const int kb = (int)(r_ % (unsigned)tg.nkb); r_ /= (unsigned)tg.nkb;
-    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
-    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
-    const int td_ = (int)(r_ % (unsigned)tg.ntd);
-    const int n = (int)(r_ / (unsigned)tg.ntd);
+    const int kb = __builtin_amdgcn_readfirstlane((int)(r_ % (unsigned)tg.nkb)); r_ /= (unsigned)tg.nkb;
+    const int tw_ = __builtin_amdgcn_readfirstlane((int)(r_ % (unsigned)tg.ntw)); r_ /= (unsigned)tg.ntw;
+    const int th_ = __builtin_amdgcn_readfirstlane((int)(r_ % (unsigned)tg.nth)); r_ /= (unsigned)tg.nth;
+    const int td_ = __builtin_amdgcn_readfirstlane((int)(r_ % (unsigned)tg.ntd));
+    const int n = __builtin_amdgcn_readfirstlane((int)(r_ / (unsigned)tg.ntd));
 
     const int C = g.C1 + g.C2;
     const int nch = C >> 5;
-    const int EHW = tg.EH * tg.EW;
-    const int nx = tg.nslots * 8;
     const int od0 = td_ * 4, oh0 = th_ * 4, ow0 = tw_ * 8;
     const int iz0 = od0 - 1, iy0 = oh0 - 1, ix0 = ow0 - 1;
 
@@ -342,14 +378,27 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = wave == 1 ? 1.f : -1.f;
+    const v2f sg2 = {sg, sg};
     // quad i: d-plane i >> 3, quad row (i >> 2) & 1, quad column i & 3; patch origin slot
-    const int sbase = ((i >> 3) * tg.EH + 2 * ((i >> 2) & 1)) * tg.EW + 2 * (i & 3);
-    const float4 *xa4 = reinterpret_cast<const float4 *>(Xs + (size_t)(sbase + ra * tg.EW) * WXS + h * 16);
-    const float4 *xb4 = reinterpret_cast<const float4 *>(Xs + (size_t)(sbase + rb * tg.EW) * WXS + h * 16);
-    // weights: step (cc, gz, e) -> block ((cc*3 + gz)*4 + a)*4 + e of 4 quarters (b) x [h][k][4]
-    const size_t uq = (size_t)2 * tg.K * 4;  // floats between the b quarters
-    const size_t ustep = 4 * uq;             // floats between consecutive e steps
-    const float *ulane = u + (((size_t)h * tg.K + kb * 32 + i) << 2) + (size_t)wave * 4 * ustep;
+    const int sbase = ((i >> 3) * W2EH + 2 * ((i >> 2) & 1)) * W2EW + 2 * (i & 3);
+    const v4f *xa4 = reinterpret_cast<const v4f *>(Xs + (size_t)(sbase + ra * W2EW) * WXS + h * 16);
+    const v4f *xb4 = reinterpret_cast<const v4f *>(Xs + (size_t)(sbase + rb * W2EW) * WXS + h * 16);
+    // weights: step (cc, gz, e) -> block ((cc*3 + gz)*4 + a)*4 + e of 4 quarters (b) x [h][k][4]; the block address is
+    // wave-uniform (scalar registers), the lane adds a 32-bit offset
+    const unsigned uq = 2u * tg.K * 4;  // floats between the b quarters
+    const unsigned ustep = 4 * uq;      // floats between consecutive e steps
+    const unsigned ulane = ((unsigned)(h * tg.K + kb * 32 + i)) << 4;  // BYTES: scalar base + 32-bit lane offset loads
+    const float *uwave = u + (size_t)wave * 4 * ustep;
+
+    // halo staging without divisions: 240 threads cover three (z, y) rows of 10 slots x 8 float4 per pass; pass q holds
+    // rows 3q .. 3q+2, i.e. plane q >> 1 and y = r3 + 3 * (q & 1).  Everything lane-dependent is computed once per item.
+    const bool st_act = tid < 240;
+    const int r3 = tid / 80, rem = tid - r3 * 80;
+    const int sx = rem >> 3, part = rem & 7;
+    const int iw = ix0 + sx, ihA = iy0 + r3, ihB = ihA + 3;
+    const bool okw = st_act && iw >= 0 && iw < g.Wi;
+    const bool okA = okw && ihA >= 0 && ihA < g.Hi, okB = okw && ihB >= 0 && ihB < g.Hi;
+    v4f *lds_st = reinterpret_cast<v4f *>(Xs + (size_t)(r3 * W2EW + sx) * WXS + part * 4);
 
     f32x16 acc[4];
 #pragma unroll
@@ -366,66 +415,85 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
         } else {
             src = a2; Cs = g.C2; cofs = c0 - g.C1;
         }
-        const float *uc = ulane + (size_t)cc * 3 * 16 * ustep;  // 3 planes x 4 position rows x 4 steps
+        const float *uc = uwave + (size_t)cc * 3 * 16 * ustep;  // 3 planes x 4 position rows x 4 steps
         float4 wb[2][4];
 #pragma unroll
-        for (int b = 0; b < 4; b++) wb[0][b] = *reinterpret_cast<const float4 *>(uc + b * uq);
+        for (int b = 0; b < 4; b++)
+            wb[0][b] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(uc + b * uq) + ulane);
         __syncthreads();  // every wave is done with the previous chunk's halo
-        int tid_ = tid;   // see k_fwd_wino: keeps the slot index math out of the MFMA loop's live ranges
-        asm volatile("" : "+v"(tid_));
-        for (int base = 0; base < WXR; base += 4) {
-            float4 v[4];
+        {
+            // byte offsets inside a (n, z) plane; only used when okA / okB (host checks Hi * Wi * Cs * 4 < 2^31)
+            const unsigned offA = (unsigned)((ihA * g.Wi + iw) * Cs + cofs + part * 4) << 2;
+            const unsigned offB = offA + ((unsigned)(3 * g.Wi * Cs) << 2);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int idx = (base + q) * 256 + tid_;
-                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nx && !(kAblate && (tg.dbg & 1))) {
-                    const int slot = idx >> 3;
-                    const int ez = (slot * tg.magHW) >> 16, rem = slot - ez * EHW;
-                    const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
-                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
-                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
-                        v[q] = *reinterpret_cast<const float4 *>(
-                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid_ & 7) * 4);
+            for (int base = 0; base < WXR; base += W2B) {
+                v4f v[W2B];
+#pragma unroll
+                for (int q = 0; q < W2B; q++) {
+                    const int pq = base + q, id = iz0 + (pq >> 1);  // plane: wave-uniform
+                    const float *plane = src + ((size_t)n * g.Di + id) * g.Hi * g.Wi * Cs;
+                    const bool ok = ((pq & 1) ? okB : okA) && id >= 0 && id < g.Di && !(kAblate && (tg.dbg & 1));
+                    v[q] = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (ok)
+                        v[q] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(plane) + ((pq & 1) ? offB : offA));
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int idx = (base + q) * 256 + tid_;
-                if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * WXS + (idx & 7) * 4) = v[q];
+                for (int q = 0; q < W2B; q++) {
+                    const int pq = base + q;
+                    if (st_act) lds_st[((pq >> 1) * W2EHW + 3 * (pq & 1) * W2EW) * (WXS / 4)] = v[q];
+                }
             }
         }
         __syncthreads();
+        // 12 steps (plane gz, channel quarter e).  The patch of step s + 1 is read from LDS before the MFMAs of step s
+        // are issued, so its latency hides behind them: the P[ra] rows go to a second register set (parity e & 1), the
+        // P[rb] rows back into the registers the transform of step s has just released.
+        v4f pa[2][4], pb[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            pa[0][c] = xa4[c * (WXS / 4)];
+            pb[c] = xb4[c * (WXS / 4)];
+        }
 #pragma unroll 1
         for (int gz = 0; gz < 3; gz++) {
-            const int po = gz * EHW * (WXS / 4);  // float4 offset of the plane
+            const int po = gz * W2EHW * (WXS / 4);  // float4 offset of the plane
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 {   // next step's weights: (gz, e + 1), (gz + 1, 0); the chunk's last step re-reads its own
                     const int nxt = (gz == 2 && e == 3) ? gz * 16 + e : (e == 3 ? (gz + 1) * 16 : gz * 16 + e + 1);
                     if (!(kAblate && (tg.dbg & 4))) {
+                        const float *un = uc + (size_t)nxt * ustep;  // wave-uniform
 #pragma unroll
                         for (int b = 0; b < 4; b++)
-                            wb[(e + 1) & 1][b] = *reinterpret_cast<const float4 *>(uc + (size_t)nxt * ustep + b * uq);
+                            wb[(e + 1) & 1][b] =
+                                *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(un + b * uq) + ulane);
                     }
                 }
-                float4 R[4];
+                // next step's patch (the last step of the chunk reads plane 3 = a valid, unused halo plane)
+                const int pn = (e == 3) ? po + W2EHW * (WXS / 4) : po + e + 1;
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    R[c] = f4_axpy(sg, xb4[po + c * (WXS / 4) + e], xa4[po + c * (WXS / 4) + e]);
-                float4 V[4];
-                V[0] = f4_sub(R[0], R[2]);
-                V[1] = f4_add(R[1], R[2]);
-                V[2] = f4_sub(R[2], R[1]);
-                V[3] = f4_sub(R[1], R[3]);
+                for (int c = 0; c < 4; c++) pa[(e + 1) & 1][c] = xa4[pn + c * (WXS / 4)];
+                __builtin_amdgcn_sched_barrier(0);
+                v2f Vl[4], Vh[4];
 #pragma unroll
-                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].x, wb[e & 1][b].x, acc[b], 0, 0, 0);
+                for (int c = 0; c < 4; c++) {
+                    Vl[c] = pa[e & 1][c].xy;
+                    Vh[c] = pa[e & 1][c].zw;
+                }
+                Vl[1] = wino2_input_transform(sg2, Vl[0], Vl[1], Vl[2], Vl[3], pb[0].xy, pb[1].xy, pb[2].xy, pb[3].xy);
+                Vh[1] = wino2_input_transform(sg2, Vh[0], Vh[1], Vh[2], Vh[3], pb[0].zw, pb[1].zw, pb[2].zw, pb[3].zw);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].y, wb[e & 1][b].y, acc[b], 0, 0, 0);
+                for (int c = 0; c < 4; c++) pb[c] = xb4[pn + c * (WXS / 4)];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].z, wb[e & 1][b].z, acc[b], 0, 0, 0);
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vl[b].x, wb[e & 1][b].x, acc[b], 0, 0, 0);
 #pragma unroll
-                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[b].w, wb[e & 1][b].w, acc[b], 0, 0, 0);
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vl[b].y, wb[e & 1][b].y, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vh[b].x, wb[e & 1][b].z, acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vh[b].y, wb[e & 1][b].w, acc[b], 0, 0, 0);
             }
         }
     }
@@ -447,27 +515,46 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     }
     __syncthreads();
     // wave (yr, yc) = (wave >> 1, wave & 1) finishes output voxel (yr, yc) of each quad from column tile t_yc of
-    // position rows {0,1,2} (yr = 0: sum) or {1,2,3} (yr = 1: t[1] - t[2] - t[3])
+    // position rows {0,1,2} (yr = 0: sum) or {1,2,3} (yr = 1: t[1] - t[2] - t[3]).  Accumulator row r of lane half h is
+    // quad (r & 3) + 8 * (r >> 2) + 4 * h: column r & 3 and plane r >> 2 are wave-uniform, the quad row is h.
     const int yr = wave >> 1, yc = wave & 1;
     const float *xt = Xs + (size_t)yc * 1024 + lane;
     const int k = kb * 32 + i;
     const float bv = bias ? bias[k] : 0.f;
+    const int oh = oh0 + 2 * h + yr;
+    const bool okh = oh < g.Ho;
     float ssum = 0.f, ssq = 0.f;  // InstanceNorm statistics of this tile (optional epilogue)
+    if (g.K2 == 0 || g.K1 == g.K2) {
+        // one voxel stride for every lane: per-lane column pointer (once) + a scalar voxel offset per r
+        const int Ks = g.K1;
+        float *ylane = (k < g.K1 ? y1 + k : y2 + (k - g.K1)) + (size_t)(oh * g.Wy) * Ks;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
-                    tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
-        const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
-        const int pi = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int od = od0 + (pi >> 3), oh = oh0 + 2 * ((pi >> 2) & 1) + yr, ow = ow0 + 2 * (pi & 3) + yc;
-        if (od < g.Do && oh < g.Ho && ow < g.Wo) {
-            const size_t ov = (((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + ow;
-            if (k < g.K1)
-                y1[ov * g.K1 + k] = val;
-            else
-                y2[ov * g.K2 + (k - g.K1)] = val;
-            ssum += val;
-            ssq += val * val;
+        for (int r = 0; r < 16; r++) {
+            const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
+                        tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
+            const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
+            const int od = od0 + (r >> 2), ow = ow0 + 2 * (r & 3) + yc;  // wave-uniform
+            const size_t uo = ((((size_t)n * g.Dy + od) * g.Hy) * g.Wy + ow) * Ks;
+            if (od < g.Do && ow < g.Wo && okh) {
+                ylane[uo] = val;
+                ssum += val;
+                ssq += val * val;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
+                        tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
+            const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
+            const int od = od0 + (r >> 2), ow = ow0 + 2 * (r & 3) + yc;
+            if (od < g.Do && ow < g.Wo && okh) {
+                const size_t ov = (((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + ow;
+                if (k < g.K1)
+                    y1[ov * g.K1 + k] = val;
+                else
+                    y2[ov * g.K2 + (k - g.K1)] = val;
+            }
         }
     }
     if (stats != nullptr) {  // block-uniform
