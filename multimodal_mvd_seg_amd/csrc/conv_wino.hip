@@ -434,8 +434,11 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
                     const float *plane = src + ((size_t)n * g.Di + id) * g.Hi * g.Wi * Cs;
                     const bool ok = ((pq & 1) ? okB : okA) && id >= 0 && id < g.Di && !(kAblate && (tg.dbg & 1));
                     v[q] = v4f{0.f, 0.f, 0.f, 0.f};
-                    if (ok)
-                        v[q] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(plane) + ((pq & 1) ? offB : offA));
+                    if (ok) {
+                        unsigned o = (pq & 1) ? offB : offA;
+                        asm("" : "+v"(o));  // scalar plane base + 32-bit lane offset (see the weight loads)
+                        v[q] = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(plane) + o);
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < W2B; q++) {
@@ -463,10 +466,14 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
                     const int nxt = (gz == 2 && e == 3) ? gz * 16 + e : (e == 3 ? (gz + 1) * 16 : gz * 16 + e + 1);
                     if (!(kAblate && (tg.dbg & 4))) {
                         const float *un = uc + (size_t)nxt * ustep;  // wave-uniform
+                        // opaque 32-bit copy: the zero-extension stays in this block, so the loads select the
+                        // scalar-base + 32-bit-offset form (no 64-bit VALU add per load)
+                        unsigned ul = ulane;
+                        asm("" : "+v"(ul));
 #pragma unroll
                         for (int b = 0; b < 4; b++)
                             wb[(e + 1) & 1][b] =
-                                *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(un + b * uq) + ulane);
+                                *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(un + b * uq) + ul);
                     }
                 }
                 // next step's patch (the last step of the chunk reads plane 3 = a valid, unused halo plane)

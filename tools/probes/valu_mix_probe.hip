@@ -84,6 +84,13 @@ __global__ __launch_bounds__(256, 3) void kop(float *out, const float *in, int i
     v2f v[8];
     for (int j = 0; j < 8; j++) v[j] = v2f{in[threadIdx.x + 32 * j], in[threadIdx.x + 32 * j + 1]};
     v2f c = {in[threadIdx.x + 7], in[threadIdx.x + 8]}, d = {in[threadIdx.x + 9], in[threadIdx.x + 10]};
+    __shared__ float lds[4096];
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    const unsigned ldsaddr = (unsigned)(threadIdx.x & 63) * 16;
+    unsigned sreg = 0;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f wide[2] = {};
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int m = 0; m < 16; m++) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m & 3], 0, 0, 0);
@@ -96,12 +103,18 @@ __global__ __launch_bounds__(256, 3) void kop(float *out, const float *in, int i
             if (OP == 4) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[n & 7].x) : "v"(c.x));
             if (OP == 5) asm volatile("v_mov_b32 %0, %1" : "+v"(v[n & 7].x) : "v"(c.x));
             if (OP == 6) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v[n & 7]) : "v"(c));
+            if (OP == 7) asm volatile("ds_read_b32 %0, %1" : "=v"(v[n & 7].y) : "v"(ldsaddr) : "memory");
+            if (OP == 8) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sreg));
+            if (OP == 9) asm volatile("s_nop 0");
+            if (OP == 10) asm volatile("ds_read_b128 %0, %1" : "=v"(wide[n & 1]) : "v"(ldsaddr) : "memory");
         }
     }
     float s = 0;
     for (int j = 0; j < 4; j++)
         for (int r = 0; r < 16; r++) s += acc[j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)");
     for (int j = 0; j < 8; j++) s += v[j].x + v[j].y;
+    s += wide[0].x + wide[1].y + (float)sreg;
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -152,6 +165,8 @@ int main() {
         runop<0, 64>("v_fma_f32", out, in, base); runop<1, 64>("v_pk_fma_f32", out, in, base); runop<2, 64>("v_pk_add_f32", out, in, base);
         runop<3, 64>("v_add_f32", out, in, base); runop<4, 64>("v_add_u32", out, in, base); runop<5, 64>("v_mov_b32", out, in, base);
         runop<6, 64>("v_pk_mul_f32", out, in, base);
+        runop<7, 64>("ds_read_b32", out, in, base); runop<10, 64>("ds_read_b128", out, in, base);
+        runop<8, 64>("s_add_u32", out, in, base); runop<9, 64>("s_nop 0", out, in, base);
     }
     runi<0, 1>(out, in); runi<2, 1>(out, in); runi<4, 1>(out, in); runi<8, 1>(out, in); runi<12, 1>(out, in); runi<16, 1>(out, in);
     runi<0, 3>(out, in); runi<2, 3>(out, in); runi<4, 3>(out, in); runi<8, 3>(out, in); runi<12, 3>(out, in); runi<16, 3>(out, in);
