@@ -166,7 +166,7 @@ int main() {
         runop<3, 64>("v_add_f32", out, in, base); runop<4, 64>("v_add_u32", out, in, base); runop<5, 64>("v_mov_b32", out, in, base);
         runop<6, 64>("v_pk_mul_f32", out, in, base);
         runop<7, 64>("ds_read_b32", out, in, base); runop<10, 64>("ds_read_b128", out, in, base);
-        runop<8, 64>("s_add_u32", out, in, base); runop<9, 64>("s_nop 0", out, in, base);
+        runop<9, 64>("s_nop 0", out, in, base);
     }
     runi<0, 1>(out, in); runi<2, 1>(out, in); runi<4, 1>(out, in); runi<8, 1>(out, in); runi<12, 1>(out, in); runi<16, 1>(out, in);
     runi<0, 3>(out, in); runi<2, 3>(out, in); runi<4, 3>(out, in); runi<8, 3>(out, in); runi<12, 3>(out, in); runi<16, 3>(out, in);
