@@ -970,16 +970,19 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
         for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 256 + tid) * 4) = rb[u];
     };
     // operands of k-step s2 (k = voxel pair).  Byte offsets: slot*128 + lane column; the per-tap part is hoisted.
+    // The lane half h is the second voxel of the pair: s2 is even and TW a power of two >= 2, so (s2 + h) only changes
+    // wx by h -- that part is a per-lane constant folded into aoff / boff, and the step's slot offset is wave-uniform
+    // (scalar ALU: VALU instructions are paid in MFMA issue cycles).
     int aoff[TPW], boff[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
-        aoff[j] = ta[j] * 128 + i * 4;
-        boff[j] = tb[j] * 128 + i * 4;
+        aoff[j] = ta[j] * 128 + i * 4 + h * g.sa[2] * 128;
+        boff[j] = tb[j] * 128 + i * 4 + h * g.sb[2] * 128;
     }
     const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
     constexpr int NAV = SH == 2 ? 1 : TPW, NBV = SH == 1 ? 1 : TPW;
     auto read_ops = [&](int s2, float (&av)[NAV], float (&bv)[NBV]) {
-        const int v = (s2 < TV ? s2 : TV - 2) + h;  // the tail prefetch re-reads the last step (harmless)
+        const int v = s2 < TV ? s2 : TV - 2;  // the tail prefetch re-reads the last step (harmless); wave-uniform
         const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
         const int sa_ = (((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2]) * 128;
         const int sb_ = (((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2]) * 128;

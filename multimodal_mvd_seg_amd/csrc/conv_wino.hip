@@ -348,6 +348,7 @@ __device__ __forceinline__ v2f wino2_input_transform(v2f sg, v2f &a0, v2f a1, v2
 #endif
 constexpr int W2B = MVD_W2B;  // staging loads in flight per thread before the LDS stores
 constexpr int W2EH = 6, W2EW = 10, W2EHW = 60;  // halo of the 4 x 4 x 8 tile: 6 x 6 x 10 slots
+__device__ __forceinline__ constexpr int w2_coff(int c) { return (c >> 1) + 5 * (c & 1); }  // slot offset of patch column c
 
 __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const WinoTile tg, const float *__restrict__ a1,
                                                       const float *__restrict__ a2, const float *__restrict__ u,
@@ -379,8 +380,12 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = wave == 1 ? 1.f : -1.f;
     const v2f sg2 = {sg, sg};
-    // quad i: d-plane i >> 3, quad row (i >> 2) & 1, quad column i & 3; patch origin slot
-    const int sbase = ((i >> 3) * W2EH + 2 * ((i >> 2) & 1)) * W2EW + 2 * (i & 3);
+    // LDS layout: each 10-slot halo row holds the even x first (x -> (x >> 1) + 5 * (x & 1)), and quad i = (plane i & 3,
+    // column (i >> 2) & 3, quad row i >> 4).  With the 144-byte slot stride this is the assignment for which all eight
+    // ds_read_b128 of a step are bank-conflict free (4.5 instead of 12.9 LDS cycles per read: tools/probes/
+    // lds_pattern_probe.hip sweeps every bit assignment).  The patch columns c = 0..3 of a quad (x = 2 col + c) sit at
+    // slot offsets 0, 5, 1, 6 from the quad's origin.
+    const int sbase = ((i & 3) * W2EH + 2 * (i >> 4)) * W2EW + ((i >> 2) & 3);
     const v4f *xa4 = reinterpret_cast<const v4f *>(Xs + (size_t)(sbase + ra * W2EW) * WXS + h * 16);
     const v4f *xb4 = reinterpret_cast<const v4f *>(Xs + (size_t)(sbase + rb * W2EW) * WXS + h * 16);
     // weights: step (cc, gz, e) -> block ((cc*3 + gz)*4 + a)*4 + e of 4 quarters (b) x [h][k][4]; the block address is
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     const int iw = ix0 + sx, ihA = iy0 + r3, ihB = ihA + 3;
     const bool okw = st_act && iw >= 0 && iw < g.Wi;
     const bool okA = okw && ihA >= 0 && ihA < g.Hi, okB = okw && ihB >= 0 && ihB < g.Hi;
-    v4f *lds_st = reinterpret_cast<v4f *>(Xs + (size_t)(r3 * W2EW + sx) * WXS + part * 4);
+    v4f *lds_st = reinterpret_cast<v4f *>(Xs + (size_t)(r3 * W2EW + (sx >> 1) + 5 * (sx & 1)) * WXS + part * 4);
 
     f32x16 acc[4];
 #pragma unroll
@@ -454,8 +459,8 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
         v4f pa[2][4], pb[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            pa[0][c] = xa4[c * (WXS / 4)];
-            pb[c] = xb4[c * (WXS / 4)];
+            pa[0][c] = xa4[w2_coff(c) * (WXS / 4)];
+            pb[c] = xb4[w2_coff(c) * (WXS / 4)];
         }
 #pragma unroll 1
         for (int gz = 0; gz < 3; gz++) {
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
                 // next step's patch (the last step of the chunk reads plane 3 = a valid, unused halo plane)
                 const int pn = (e == 3) ? po + W2EHW * (WXS / 4) : po + e + 1;
 #pragma unroll
-                for (int c = 0; c < 4; c++) pa[(e + 1) & 1][c] = xa4[pn + c * (WXS / 4)];
+                for (int c = 0; c < 4; c++) pa[(e + 1) & 1][c] = xa4[pn + w2_coff(c) * (WXS / 4)];
                 __builtin_amdgcn_sched_barrier(0);
                 v2f Vl[4], Vh[4];
 #pragma unroll
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
                 Vh[1] = wino2_input_transform(sg2, Vh[0], Vh[1], Vh[2], Vh[3], pb[0].zw, pb[1].zw, pb[2].zw, pb[3].zw);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < 4; c++) pb[c] = xb4[pn + c * (WXS / 4)];
+                for (int c = 0; c < 4; c++) pb[c] = xb4[pn + w2_coff(c) * (WXS / 4)];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vl[b].x, wb[e & 1][b].x, acc[b], 0, 0, 0);
@@ -523,26 +528,28 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     __syncthreads();
     // wave (yr, yc) = (wave >> 1, wave & 1) finishes output voxel (yr, yc) of each quad from column tile t_yc of
     // position rows {0,1,2} (yr = 0: sum) or {1,2,3} (yr = 1: t[1] - t[2] - t[3]).  Accumulator row r of lane half h is
-    // quad (r & 3) + 8 * (r >> 2) + 4 * h: column r & 3 and plane r >> 2 are wave-uniform, the quad row is h.
+    // quad q = (r & 3) + 8 * (r >> 2) + 4 * h = (plane r & 3, column 2 * ((r >> 2) & 1) + h, quad row r >> 3): plane,
+    // quad row and the column's upper bit are wave-uniform, the lane half moves the output by two voxels along W.
     const int yr = wave >> 1, yc = wave & 1;
     const float *xt = Xs + (size_t)yc * 1024 + lane;
     const int k = kb * 32 + i;
     const float bv = bias ? bias[k] : 0.f;
-    const int oh = oh0 + 2 * h + yr;
-    const bool okh = oh < g.Ho;
+    const int owl = ow0 + yc + 2 * h;                          // + 4 * ((r >> 2) & 1)
+    const bool okw0 = owl < g.Wo, okw1 = owl + 4 < g.Wo;
     float ssum = 0.f, ssq = 0.f;  // InstanceNorm statistics of this tile (optional epilogue)
     if (g.K2 == 0 || g.K1 == g.K2) {
         // one voxel stride for every lane: per-lane column pointer (once) + a scalar voxel offset per r
         const int Ks = g.K1;
-        float *ylane = (k < g.K1 ? y1 + k : y2 + (k - g.K1)) + (size_t)(oh * g.Wy) * Ks;
+        float *ylane = (k < g.K1 ? y1 + k : y2 + (k - g.K1)) + (size_t)(2 * h) * Ks;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
                         tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
             const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
-            const int od = od0 + (r >> 2), ow = ow0 + 2 * (r & 3) + yc;  // wave-uniform
-            const size_t uo = ((((size_t)n * g.Dy + od) * g.Hy) * g.Wy + ow) * Ks;
-            if (od < g.Do && ow < g.Wo && okh) {
+            const int od = od0 + (r & 3), oh = oh0 + 2 * (r >> 3) + yr;   // wave-uniform
+            const int owu = ow0 + yc + 4 * ((r >> 2) & 1);                // wave-uniform part of ow
+            const size_t uo = ((((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + owu) * Ks;
+            if (od < g.Do && oh < g.Ho && (((r >> 2) & 1) ? okw1 : okw0)) {
                 ylane[uo] = val;
                 ssum += val;
                 ssq += val * val;
@@ -554,8 +561,9 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
                         tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
             const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
-            const int od = od0 + (r >> 2), ow = ow0 + 2 * (r & 3) + yc;
-            if (od < g.Do && ow < g.Wo && okh) {
+            const int od = od0 + (r & 3), oh = oh0 + 2 * (r >> 3) + yr;
+            const int ow = owl + 4 * ((r >> 2) & 1);
+            if (od < g.Do && oh < g.Ho && ow < g.Wo) {
                 const size_t ov = (((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + ow;
                 if (k < g.K1)
                     y1[ov * g.K1 + k] = val;
