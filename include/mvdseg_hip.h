@@ -77,6 +77,12 @@ size_t mvd_wino_weight_elems(int C, int K);
 /* 0 = direct engines only, 1 = F(2,3) along W, 2 = F(2x2,3x3) over H and W (default; env MVD_WINO) */
 int mvd_wino_mode(void);
 int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream);
+/* Every conv weight of a network re-packed in ONE launch (the per-layer pack entries are launch-bound; called by the
+ * fused optimizer right after the SGD update).  Host tables of n jobs: w[q] the torch-layout weight, wf/wb the
+ * mvd_pack_weight outputs, uf/ub the mvd_pack_weight_wino outputs (null entries are skipped; uf/ub need MVD_WINO=2). */
+int mvd_pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf,
+                           float *const *ub, const int *K, const int *C, const int *T, const int *transposed,
+                           void *stream);
 int mvd_conv3d_fwd_wino(const float *x1, int C1, const float *x2, int C2, const float *wf, const float *uf,
                         const float *bias, float *y, int N, int D, int H, int W, int K, const int ksize[3],
                         const int stride[3], void *ws, size_t ws_bytes, void *stream);

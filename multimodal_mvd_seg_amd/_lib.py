@@ -37,6 +37,7 @@ SIGNATURES = {
     "mvd_wino_mode": (c_int, []),
     "mvd_wino_weight_elems": (c_size_t, [c_int, c_int]),
     "mvd_pack_weight_wino": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "mvd_pack_weights_batch": (c_int, [c_int] + [_P] * 9 + [_P]),
     "mvd_conv3d_fwd_wino": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                     c_size_t, _P]),
     "mvd_conv_stats_tiles": (c_size_t, [c_int, c_int, c_int]),

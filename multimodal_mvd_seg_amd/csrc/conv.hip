@@ -425,6 +425,22 @@ int mvd_conv3d_fwd_wino_stats(const float *x1, int C1, const float *x2, int C2, 
                            stats_done);
 }
 
+int mvd_pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf,
+                           float *const *ub, const int *K, const int *C, const int *T, const int *transposed,
+                           void *stream) {
+    MVD_REQUIRE(n > 0 && w && wf && wb && uf && ub && K && C && T && transposed, "pack_weights_batch: null table");
+    for (int q = 0; q < n; q++) {
+        MVD_REQUIRE(w[q] && (wf[q] || wb[q] || uf[q] || ub[q]), "pack_weights_batch: job without source or destination");
+        MVD_REQUIRE(K[q] > 0 && C[q] > 0 && T[q] > 0 && T[q] <= MVD_MAX_TAPS, "pack_weights_batch: bad K / C / T");
+        if (uf[q] || ub[q]) {
+            MVD_REQUIRE(wino_mode() == 2, "pack_weights_batch: Winograd tables need MVD_WINO=2 (F(2x2,3x3) layout)");
+            MVD_REQUIRE(T[q] == 27 && !transposed[q] && K[q] % 32 == 0 && C[q] % 32 == 0,
+                        "pack_weights_batch: Winograd tables need a 3x3x3 conv with C %% 32 == 0 and K %% 32 == 0");
+        }
+    }
+    return pack_weights_batch(n, w, wf, wb, uf, ub, K, C, T, transposed, as_stream(stream));
+}
+
 int mvd_pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, void *stream) {
     MVD_REQUIRE(w && (uf || ub) && K > 0 && C > 0, "pack_weight_wino: bad arguments");
     MVD_REQUIRE(K % 32 == 0 && C % 32 == 0, "pack_weight_wino: needs C %% 32 == 0 and K %% 32 == 0");

@@ -272,10 +272,8 @@ __host__ __device__ inline size_t u2idx(int K, int cc, int gz, int a, int b, int
     return ((((((((size_t)cc * 3 + gz) * 4 + a) * 4 + (e >> 2)) * 4 + b) * 2 + h) * K + k) << 2) + (e & 3);
 }
 
-__global__ void k_pack_wino2(const float *__restrict__ w, float *__restrict__ uf, float *__restrict__ ub, int K, int C) {
-    const long total = (long)3 * 16 * C * K;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+__device__ __forceinline__ void pack_wino2_item(const float *__restrict__ w, float *__restrict__ uf,
+                                                float *__restrict__ ub, int K, int C, long idx) {
     const int k = (int)(idx % K);
     long r = idx / K;
     const int c = (int)(r % C);
@@ -299,6 +297,125 @@ __global__ void k_pack_wino2(const float *__restrict__ w, float *__restrict__ uf
             for (int j = 0; j < 3; j++) s += G[a][i] * G[b][j] * wp[((2 - gz) * 3 + (2 - i)) * 3 + (2 - j)];
         ub[u2idx(C, k >> 5, gz, a, b, (k >> 4) & 1, c, k & 15)] = s;
     }
+}
+
+__global__ void k_pack_wino2(const float *__restrict__ w, float *__restrict__ uf, float *__restrict__ ub, int K, int C) {
+    const long total = (long)3 * 16 * C * K;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    pack_wino2_item(w, uf, ub, K, C, idx);
+}
+
+// ---------------------------------------------------------------------------------------------- one launch for all layers
+// Every conv weight of the network re-packed in ONE launch after the optimizer step (the per-layer pack kernels are
+// launch-bound: 39 launches of 17-26 us per step).  Jobs travel in the kernel argument; a workgroup finds its job by a
+// scalar scan over the (at most PACK_MAX_JOBS) block ranges.
+struct PackJob {
+    const float *w;
+    float *wf, *wb, *uf, *ub;
+    int K, C, T, transposed;
+    unsigned blk_begin;
+    int tiled;  // 1: 3x3x3 conv with C % 32 == 0 and K % 32 == 0 -> one workgroup per 16 k x 16 c tile (through LDS)
+};
+constexpr int PACK_MAX_JOBS = 48;
+struct PackBatch {
+    int n;
+    PackJob j[PACK_MAX_JOBS];
+};
+
+// Tiled jobs: the workgroup reads its 16 x 16 x 27 block of the torch tensor as 16 contiguous 1.7 KB runs into LDS and
+// writes every packed layout in contiguous 256-byte .. 1 KB runs (the element-wise kernels read with a C*27*4-byte
+// lane stride).  Arithmetic and summation order are those of k_pack_weight / pack_wino2_item: bit-identical outputs.
+__global__ __launch_bounds__(256) void k_pack_batch(const PackBatch pb) {
+    __shared__ float tile[16 * 432];  // [k 16][c 16][t 27]
+    int jid = 0;
+    for (int q = 1; q < pb.n; q++)
+        if (blockIdx.x >= pb.j[q].blk_begin) jid = q;
+    const PackJob &J = pb.j[jid];
+    const unsigned lb = blockIdx.x - J.blk_begin;
+    const int tid = threadIdx.x;
+    if (!J.tiled) {
+        const long i = (long)lb * 256 + tid;
+        if (i >= (long)J.K * J.C * J.T) return;
+        const int k = (int)(i % J.K), c = (int)((i / J.K) % J.C), t = (int)(i / ((long)J.K * J.C));  // wf order [t][c][k]
+        const float v = J.transposed ? J.w[((size_t)c * J.K + k) * J.T + t] : J.w[((size_t)k * J.C + c) * J.T + t];
+        if (J.wf) J.wf[widx(wl_ck(J.C), J.T, J.C, J.K, t, c, k)] = v;
+        if (J.wb) J.wb[widx(wl_ck(J.K), J.T, J.K, J.C, t, k, c)] = v;
+        return;
+    }
+    const int K = J.K, C = J.C;
+    const int nct = C >> 4;
+    const int k0 = (int)(lb / (unsigned)nct) * 16, c0 = (int)(lb % (unsigned)nct) * 16;
+    for (int idx = tid; idx < 16 * 432; idx += 256) {
+        const int r = idx / 432, o = idx - r * 432;
+        tile[idx] = J.w[((size_t)(k0 + r) * C + c0) * 27 + o];
+    }
+    __syncthreads();
+    const int hi = tid >> 4, lo = tid & 15;
+    if (J.wf) {  // [cc][t][h][k][16 e], c = c0 + lo, k = k0 + hi
+        const int cc = c0 >> 5, h = (c0 >> 4) & 1;
+        for (int t = 0; t < 27; t++)
+            J.wf[((((size_t)cc * 27 + t) * 2 + h) * K + k0 + hi) * 16 + lo] = tile[hi * 432 + lo * 27 + t];
+    }
+    if (J.wb) {  // [kk][t][hk][c][16 ek], k = k0 + lo, c = c0 + hi
+        const int kk = k0 >> 5, hk = (k0 >> 4) & 1;
+        for (int t = 0; t < 27; t++)
+            J.wb[((((size_t)kk * 27 + t) * 2 + hk) * C + c0 + hi) * 16 + lo] = tile[lo * 432 + hi * 27 + t];
+    }
+    if (J.uf || J.ub) {
+        const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+        const int q4 = tid >> 6, mid = (tid >> 2) & 15, l4 = tid & 3;
+        // uf: c = c0 + q4 * 4 + l4, k = k0 + mid;  ub: k = k0 + q4 * 4 + l4, c = c0 + mid
+        const float *wu = tile + mid * 432 + (q4 * 4 + l4) * 27;
+        const float *wv = tile + (q4 * 4 + l4) * 432 + mid * 27;
+        for (int pos = 0; pos < 48; pos++) {
+            const int b = pos & 3, a_ = (pos >> 2) & 3, gz = pos >> 4;
+            if (J.uf) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) s += G[a_][i] * G[b][j] * wu[(gz * 3 + i) * 3 + j];
+                const int c = c0 + q4 * 4 + l4;
+                J.uf[u2idx(K, c >> 5, gz, a_, b, (c >> 4) & 1, k0 + mid, c & 15)] = s;
+            }
+            if (J.ub) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) s += G[a_][i] * G[b][j] * wv[((2 - gz) * 3 + (2 - i)) * 3 + (2 - j)];
+                const int k = k0 + q4 * 4 + l4;
+                J.ub[u2idx(C, k >> 5, gz, a_, b, (k >> 4) & 1, c0 + mid, k & 15)] = s;
+            }
+        }
+    }
+}
+
+// jobs: host arrays of n entries.  uf / ub entries may be null (no Winograd pack for that layer).
+int pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf, float *const *ub,
+                       const int *K, const int *C, const int *T, const int *transposed, hipStream_t s) {
+    int done = 0;
+    while (done < n) {
+        PackBatch pb;
+        memset(&pb, 0, sizeof(pb));
+        unsigned blocks = 0;
+        int m = 0;
+        for (; m < PACK_MAX_JOBS && done + m < n; m++) {
+            const int q = done + m;
+            PackJob &J = pb.j[m];
+            J.w = w[q]; J.wf = wf[q]; J.wb = wb[q]; J.uf = uf[q]; J.ub = ub[q];
+            J.K = K[q]; J.C = C[q]; J.T = T[q]; J.transposed = transposed[q];
+            J.blk_begin = blocks;
+            J.tiled = (J.T == 27 && !J.transposed && J.K % 32 == 0 && J.C % 32 == 0) ? 1 : 0;
+            blocks += J.tiled ? (unsigned)((J.K / 16) * (J.C / 16)) : (unsigned)cdiv((long)J.K * J.C * J.T, 256);
+        }
+        pb.n = m;
+        if (blocks > 0) hipLaunchKernelGGL(k_pack_batch, dim3(blocks), dim3(256), 0, s, pb);
+        if (check_launch("pack_weights_batch")) return 1;
+        done += m;
+    }
+    return 0;
 }
 
 int pack_weight_wino2(const float *w, float *uf, float *ub, int K, int C, hipStream_t s) {

@@ -5,6 +5,7 @@ arithmetic operation of the hot path runs in libmvdseg_hip.so.  Activations are 
 [N,C,D,H,W] stored NDHWC (torch.channels_last_3d); logits / targets / volumes of the topology losses are planar.
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -126,6 +127,108 @@ def pack_weight(weight, transposed):
     return wf, wb
 
 
+# ---------------------------------------------------------------------------------------------- packed-weight cache (fp32)
+# The packed copies (wf / wb, Winograd uf / ub) of a conv weight live on the weight tensor object (`_mvd_pack`) and are
+# valid for one (optimizer epoch, tensor version) stamp: torch in-place writes bump the version, the fused optimizer --
+# which updates the flat buffer through a raw pointer -- bumps the epoch and re-packs every registered weight in ONE
+# launch (repack_all: mvd_pack_weights_batch).  A stale or missing entry is packed on the spot by the per-layer entries.
+_PACK_EPOCH = [0]
+_PACK_LIVE = []
+
+
+class _PackEntry:
+    __slots__ = ("transposed", "K", "C", "T", "wf", "wb", "uf", "ub", "stamp")
+
+
+def _pack_stamp(w):
+    return (_PACK_EPOCH[0], w._version)
+
+
+def _packed(weight, transposed, want_uf=False, want_ub=False):
+    w = weight.detach()
+    if not w.is_contiguous():  # no cache for a strided view: pack a contiguous copy
+        e = _PackEntry()
+        e.wf, e.wb = pack_weight(weight, transposed)
+        e.uf = e.ub = None
+        if want_uf or want_ub:
+            wc = w.contiguous()
+            K, C = wc.shape[:2]
+            n = query("mvd_wino_weight_elems", C, K)
+            e.uf = torch.empty((n,), dtype=torch.float32, device=w.device) if want_uf else None
+            e.ub = torch.empty((n,), dtype=torch.float32, device=w.device) if want_ub else None
+            call("mvd_pack_weight_wino", _p(wc), _p(e.uf), _p(e.ub), K, C, _stream())
+        return e
+    e = getattr(weight, "_mvd_pack", None)
+    stale = False
+    if e is None or e.transposed != transposed or e.wf.device != w.device:
+        e = _PackEntry()
+        e.transposed = transposed
+        if transposed:
+            e.C, e.K = w.shape[:2]
+        else:
+            e.K, e.C = w.shape[:2]
+        e.T = w[0, 0].numel()
+        e.wf = torch.empty((e.T, e.C, e.K), dtype=torch.float32, device=w.device)
+        e.wb = torch.empty((e.T, e.K, e.C), dtype=torch.float32, device=w.device)
+        e.uf = e.ub = None
+        e.stamp = None
+        weight._mvd_pack = e
+        _PACK_LIVE.append(weakref.ref(weight))
+        stale = True
+    new_wino = False
+    if (want_uf and e.uf is None) or (want_ub and e.ub is None):
+        n = query("mvd_wino_weight_elems", e.C, e.K)
+        if want_uf and e.uf is None:
+            e.uf = torch.empty((n,), dtype=torch.float32, device=w.device)
+        if want_ub and e.ub is None:
+            e.ub = torch.empty((n,), dtype=torch.float32, device=w.device)
+        new_wino = True
+    if stale or e.stamp != _pack_stamp(w):
+        call("mvd_pack_weight", _p(w), _p(e.wf), _p(e.wb), e.K, e.C, e.T, 1 if transposed else 0, _stream())
+        new_wino = e.uf is not None or e.ub is not None
+        e.stamp = _pack_stamp(w)
+    if new_wino:
+        call("mvd_pack_weight_wino", _p(w), _p(e.uf), _p(e.ub), e.K, e.C, _stream())
+    return e
+
+
+def repack_all():
+    """Called by the fused optimizer after its update: new epoch, every live cached weight re-packed in one launch."""
+    _PACK_EPOCH[0] += 1
+    jobs, alive = [], []
+    for r in _PACK_LIVE:
+        w = r()
+        e = getattr(w, "_mvd_pack", None) if w is not None else None
+        if e is None:
+            continue
+        alive.append(r)
+        d = w.detach()
+        if d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.device == e.wf.device:
+            jobs.append((d, e))
+    _PACK_LIVE[:] = alive
+    if not jobs:
+        return
+    if any(e.uf is not None or e.ub is not None for _, e in jobs) and query("mvd_wino_mode") != 2:
+        return  # the batch entry only writes the F(2x2,3x3) layout; stale entries are packed per layer
+    n = len(jobs)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    w_ = PA(*[ptr(d) for d, _ in jobs])
+    wf_ = PA(*[ptr(e.wf) for _, e in jobs])
+    wb_ = PA(*[ptr(e.wb) for _, e in jobs])
+    uf_ = PA(*[ptr(e.uf) for _, e in jobs])
+    ub_ = PA(*[ptr(e.ub) for _, e in jobs])
+    K_ = IA(*[e.K for _, e in jobs])
+    C_ = IA(*[e.C for _, e in jobs])
+    T_ = IA(*[e.T for _, e in jobs])
+    tr_ = IA(*[1 if e.transposed else 0 for _, e in jobs])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    call("mvd_pack_weights_batch", n, cast(w_), cast(wf_), cast(wb_), cast(uf_), cast(ub_), cast(K_), cast(C_), cast(T_),
+         cast(tr_), _stream())
+    for d, e in jobs:
+        e.stamp = _pack_stamp(d)
+
+
 def pack_weight_bf16(weight, transposed):
     """fp32 master weight -> bf16 (wf16, wb16) in the MFMA 32x32x16 operand layout (mvd_pack_weight_bf16)."""
     w = weight.detach()
@@ -167,23 +270,22 @@ class Conv3dFn(Function):
         bf = _is_bf16(x1)
         if x2 is not None and _is_bf16(x2) != bf:
             raise RuntimeError("conv3d: the two concatenated inputs differ in dtype")
-        wf, wb = pack_weight_bf16(weight, False) if bf else pack_weight(weight, False)
         od = [_out_dim(i, k, s) for i, k, s in zip((D, H, W), ks, stride)]
         y = empty_cl3d((N, K, *od), x1.device, x1.dtype)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, od[0] * od[1] * od[2], K), x1.device)
         ub = None
         if bf:
+            wf, wb = pack_weight_bf16(weight, False)
             call("mvd_conv3d_fwd_bf16", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
                  _p(ws), ws.numel(), _stream())
         else:
-            # fp32 3x3x3 stride-1 layers with enough tiles run the Winograd F(2,3) kernel (2/3 of the MFMA work)
+            # fp32 3x3x3 stride-1 layers with enough tiles run the Winograd kernels (4/9 of the MFMA work); the packed
+            # weights come from the per-weight cache (re-packed once per optimizer step, see repack_all)
             wino = query("mvd_conv_wino_applicable", N, D, H, W, C1, C2, K, i3(ks), i3(stride)) if len(ks) == 3 else 0
-            uf = None
-            if wino:
-                w = weight.detach().contiguous()
-                uf = torch.empty((query("mvd_wino_weight_elems", C, K),), dtype=torch.float32, device=w.device) if wino & 1 else None
-                ub = torch.empty((query("mvd_wino_weight_elems", C, K),), dtype=torch.float32, device=w.device) if wino & 2 else None
-                call("mvd_pack_weight_wino", _p(w), _p(uf), _p(ub), K, C, _stream())
+            pk = _packed(weight, False, bool(wino & 1), bool(wino & 2))
+            wf, wb = pk.wf, pk.wb
+            uf = pk.uf if wino & 1 else None
+            ub = pk.ub if wino & 2 else None
             if uf is not None:
                 # the Winograd kernel also emits the per-tile (sum, sum of squares) of its output: the InstanceNorm that
                 # follows (InstanceNormLeakyReLUFn picks them up from the tensor) skips its statistics pass
@@ -256,7 +358,11 @@ class ConvTranspose3dFn(Function):
         if Cx != C:
             raise RuntimeError("convT3d: channel mismatch")
         bf = _is_bf16(x)
-        wf, wb = pack_weight_bf16(weight, True) if bf else pack_weight(weight, True)
+        if bf:
+            wf, wb = pack_weight_bf16(weight, True)
+        else:
+            pk = _packed(weight, True)
+            wf, wb = pk.wf, pk.wb
         y = empty_cl3d((N, K, D * stride[0], H * stride[1], W * stride[2]), x.device, x.dtype)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K), x.device)
         ctx.bf = bf

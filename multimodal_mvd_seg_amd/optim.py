@@ -115,6 +115,8 @@ class FusedSGDNesterov:
              float(g['momentum']), float(g['weight_decay']), float(self.max_grad_norm or 0.0),
              1 if self._steps == 0 else 0, s)
         self._steps += 1
+        # the update went through a raw pointer: new weight epoch + every cached packed weight rebuilt in one launch
+        ops.repack_all()
 
     def state_dict(self):
         return {'momentum_buffer': self.momentum_buffer.clone(), 'steps': self._steps,

@@ -4,6 +4,7 @@ larger seeded inputs, against the CPU oracle (oracle/) evaluated on the box's ho
 
 Tolerances: fp32 results within 1e-4 abs of the oracle (north_star) -- most checks are tighter and say so;
 integer / min-max work (soft skeleton forward, connected components, argmax counts) must be bit-exact."""
+import ctypes
 import json
 import os
 
@@ -809,3 +810,62 @@ def test_device_feed_kernels_edges_and_full_size():
         d = DLD.downsample_seg(t, s)
         assert tuple(d.shape) == (1, 1, 128 // f, 128 // f, 128 // f)
         assert torch.equal(d, t[:, :, f // 2::f, f // 2::f, f // 2::f])
+
+
+@pytest.mark.gpu
+def test_packed_weight_cache_follows_every_kind_of_update():
+    """The packed copies are cached on the weight tensor: a torch in-place write (version bump), the fused optimizer
+    (raw-pointer update -> epoch bump + one batched re-pack) and a brand-new tensor at a recycled address must all be
+    seen.  Conv output after each kind of change == conv with freshly packed weights (bit-exact) and == torch."""
+    from multimodal_mvd_seg_amd import ops, optim
+    g = torch.Generator().manual_seed(3)
+    conv = torch.nn.Conv3d(32, 32, 3, padding=1).to(DEV)
+    convT = torch.nn.ConvTranspose3d(32, 32, 2, stride=2).to(DEV)
+    x = torch.randn(1, 32, 8, 8, 16, generator=g).to(DEV)
+    params = list(conv.parameters()) + list(convT.parameters())
+    opt = optim.FusedSGDNesterov(params, 0.1, weight_decay=0.0, momentum=0.9, max_grad_norm=12)
+
+    def run():
+        y = ops.Conv3dFn.apply(x, None, conv.weight, conv.bias, (1, 1, 1))
+        z = ops.ConvTranspose3dFn.apply(ops.widen(y) if hasattr(ops, "widen") and y.dtype != torch.float32 else y,
+                                        convT.weight, convT.bias, (2, 2, 2))
+        return y, z
+
+    def check(tag):
+        y, z = run()
+        ref_y = F.conv3d(x, conv.weight, conv.bias, 1, 1)
+        ref_z = F.conv_transpose3d(ref_y, convT.weight, convT.bias, 2)
+        close(y, ref_y.detach().cpu(), 2e-5, 1e-5, tag + " conv")
+        close(z, ref_z.detach().cpu(), 5e-5, 1e-5, tag + " convT")
+        return y, z
+
+    from multimodal_mvd_seg_amd._lib import call
+    call("mvd_set_wino_min_items", 1)  # Winograd tables in play
+    try:
+        check("initial")
+        assert getattr(conv.weight, "_mvd_pack", None) is not None and conv.weight._mvd_pack.uf is not None
+        with torch.no_grad():
+            conv.weight.mul_(1.5)               # version bump
+            convT.weight.add_(0.01)
+        check("after in-place write")
+        y, z = run()
+        (y.sum() + z.sum()).backward()
+        opt.step()                              # raw-pointer update + repack_all
+        e = conv.weight._mvd_pack
+        assert e.stamp == ops._pack_stamp(conv.weight.detach())
+        y1, z1 = check("after optimizer step")
+        # the batched pack == the per-layer pack, bit for bit
+        wf, wb = ops.pack_weight(conv.weight, False)
+        assert torch.equal(wf, e.wf) and torch.equal(wb, e.wb)
+        uf = torch.empty_like(e.uf)
+        call("mvd_pack_weight_wino", ctypes.c_void_p(conv.weight.data_ptr()), ctypes.c_void_p(uf.data_ptr()), None, 32, 32,
+             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(uf, e.uf)
+        wfT, wbT = ops.pack_weight(convT.weight, True)
+        assert torch.equal(wfT, convT.weight._mvd_pack.wf) and torch.equal(wbT, convT.weight._mvd_pack.wb)
+        # a fresh tensor (possibly at a recycled address) never inherits an entry
+        w2 = (conv.weight.detach() * 0.5).clone()
+        y2 = ops.Conv3dFn.apply(x, None, w2, conv.bias.detach(), (1, 1, 1))
+        close(y2, F.conv3d(x, w2, conv.bias, 1, 1).detach().cpu(), 2e-5, 1e-5, "fresh tensor")
+    finally:
+        call("mvd_set_wino_min_items", -1)
