@@ -469,9 +469,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
 //     pad: one workgroup per CU);
 //   * the packed weights are read straight from L2 one tap ahead (16 floats per lane and tap), so the tap loop has
 //     no barrier.
-constexpr int SXR = 24;  // float4 per thread: 765 slots x 8 / 256
-constexpr int SXB = 12;  // staging batch (loads in flight per thread)
-__global__ __launch_bounds__(256, 1) void k_fwd32s(const FwdGeom g, const Fwd32Tile tg, const float *__restrict__ a1,
+//   * eight waves: waves 4..7 take the second half of the 27 taps on the same tile (two waves per SIMD hide each
+//     other's LDS / L2 waits and the single accumulator chain); their tiles are added through LDS at the end.
+constexpr int SXR = 12;  // float4 per thread: 765 slots x 8 / 512
+constexpr int SXB = 6;   // staging batch of the generic path (loads in flight per thread)
+__global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32Tile tg, const float *__restrict__ a1,
                                                    const float *__restrict__ a2, const float *__restrict__ w,
                                                    const float *__restrict__ bias, float *__restrict__ y1,
                                                    float *__restrict__ y2) {
@@ -496,13 +498,30 @@ __global__ __launch_bounds__(256, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
     const int nx = tg.nslots * 8;
     const int od0 = td_ * 2, oh0 = th_ * 4, ow0 = tw_ * 8;
     const int iz0 = od0 * 2 + tg.min_off[0], iy0 = oh0 * 2 + tg.min_off[1], ix0 = ow0 * 2 + tg.min_off[2];
-    const int dl = wave & 1, kh = wave >> 1;
+    const int dl = wave & 1, kh = (wave >> 1) & 1, tap_half = wave >> 2;
+    const int tb = tap_half ? 14 : 0, nt = tap_half ? g.ntaps - 14 : 14;  // host: ntaps == 27
     const int sbase = ((2 * dl) * tg.EH + 2 * (i >> 3)) * tg.EW + 2 * (i & 7);
     const float4 *xlane = reinterpret_cast<const float4 *>(Xs + (size_t)sbase * XS + h * 16);
     const int kcol = kb * 64 + kh * 32 + i;
     // packed weights: [cc][t][h][k][16]
     const float *wlane = w + (((size_t)h * tg.K + kcol) << 4);
     const size_t wtap = (size_t)2 * tg.K * 16;
+
+    // division-free staging for the 5 x 9 x 17 footprint (every 3x3x3 stride-2 conv): 408 threads cover three 17-slot
+    // rows per pass; pass q holds plane q / 3 and rows 3 * (q % 3) + r3 (VALU work is paid in MFMA issue cycles)
+    const bool fastst = tg.EH == 9 && tg.EW == 17 && tg.nslots == 765;
+    const int r3 = tid / 136, rem = tid - r3 * 136;
+    const int sx = rem >> 3, part = rem & 7;
+    const bool st_act = tid < 408;
+    const int iw = ix0 + sx;
+    const bool okw = st_act && iw >= 0 && iw < g.Wi;
+    bool okr[3];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        const int ih = iy0 + r3 + 3 * v;
+        okr[v] = okw && ih >= 0 && ih < g.Hi;
+    }
+    float4 *lds_st = reinterpret_cast<float4 *>(Xs + (size_t)(r3 * 17 + sx) * XS + part * 4);
 
     f32x16 acc;
 #pragma unroll
@@ -518,36 +537,60 @@ __global__ __launch_bounds__(256, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
             src = a2; Cs = g.C2; cofs = c0 - g.C1;
         }
         const float *wc = wlane + (size_t)cc * g.T * wtap;
-        // weights run three taps ahead of the MFMAs (4-deep register ring): with one wave per SIMD nothing else hides an
-        // L2 round trip
+        // weights run three taps ahead of the MFMAs (4-deep register ring)
         float4 wb[4][4];
 #pragma unroll
         for (int u = 0; u < 3; u++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) wb[u][e] = *reinterpret_cast<const float4 *>(wc + (size_t)g.wt[u] * wtap + e * 4);
+            for (int e = 0; e < 4; e++) wb[u][e] = *reinterpret_cast<const float4 *>(wc + (size_t)g.wt[tb + u] * wtap + e * 4);
         __syncthreads();
-        int tid_ = tid;
-        asm volatile("" : "+v"(tid_));
-        for (int base = 0; base < SXR; base += SXB) {
-            float4 v[SXB];
+        if (fastst) {
+            const unsigned off0 = (unsigned)(((iy0 + r3) * g.Wi + iw) * Cs + cofs + part * 4) << 2;  // bytes, used when ok
+            const unsigned drow = (unsigned)(3 * g.Wi * Cs) << 2;
 #pragma unroll
-            for (int q = 0; q < SXB; q++) {
-                const int idx = (base + q) * 256 + tid_;
-                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < nx) {
-                    const int slot = idx >> 3;
-                    const int ez = slot / EHW, rem = slot - ez * EHW;
-                    const int ey = (rem * tg.magW) >> 16, ex = rem - ey * tg.EW;
-                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
-                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
-                        v[q] = *reinterpret_cast<const float4 *>(
-                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid_ & 7) * 4);
+            for (int base = 0; base < 15; base += 5) {
+                float4 v[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const int pq = base + q, id = iz0 + pq / 3;  // plane: wave-uniform
+                    const float *plane = src + ((size_t)n * g.Di + id) * g.Hi * g.Wi * Cs;
+                    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (okr[pq % 3] && id >= 0 && id < g.Di) {
+                        unsigned o = off0 + (unsigned)(pq % 3) * drow;
+                        asm("" : "+v"(o));  // scalar plane base + 32-bit lane offset
+                        v[q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(plane) + o);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const int pq = base + q;
+                    if (st_act) lds_st[((pq / 3) * 9 + 3 * (pq % 3)) * 17 * (XS / 4)] = v[q];
                 }
             }
+        } else {
+            int tid_ = tid;
+            asm volatile("" : "+v"(tid_));
+            for (int base = 0; base < SXR; base += SXB) {
+                float4 v[SXB];
 #pragma unroll
-            for (int q = 0; q < SXB; q++) {
-                const int idx = (base + q) * 256 + tid_;
-                if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * XS + (idx & 7) * 4) = v[q];
+                for (int q = 0; q < SXB; q++) {
+                    const int idx = (base + q) * 512 + tid_;
+                    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < nx) {
+                        const int slot = idx >> 3;
+                        const int ez = slot / EHW, rem2 = slot - ez * EHW;
+                        const int ey = (rem2 * tg.magW) >> 16, ex = rem2 - ey * tg.EW;
+                        const int id = iz0 + ez, ih = iy0 + ey, iw2 = ix0 + ex;
+                        if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw2 >= 0 && iw2 < g.Wi)
+                            v[q] = *reinterpret_cast<const float4 *>(
+                                src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw2) * Cs + cofs + (tid_ & 7) * 4);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SXB; q++) {
+                    const int idx = (base + q) * 512 + tid_;
+                    if (idx < nx) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * XS + (idx & 7) * 4) = v[q];
+                }
             }
         }
         __syncthreads();
@@ -555,20 +598,21 @@ __global__ __launch_bounds__(256, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
         // an in-flight MFMA reads is never the target of the next tap's ds_read
         float4 af[2][4];
         {
-            const float4 *pa = xlane + (size_t)tg.toff[0] * (XS / 4);
+            const float4 *pa = xlane + (size_t)tg.toff[tb] * (XS / 4);
 #pragma unroll
             for (int e = 0; e < 4; e++) af[0][e] = pa[e];
         }
-        for (int t0 = 0; t0 < 27; t0 += 4) {  // four taps per trip: static ring indices
+        for (int s0 = 0; s0 < nt; s0 += 4) {  // four taps per trip: static ring indices
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int t = t0 + u;
-                if (t < 27) {  // uniform
-                    const int tn = t + 3 < 27 ? t + 3 : 26;
+                const int sidx = s0 + u;
+                if (sidx < nt) {  // uniform
+                    const int t = tb + sidx;
+                    const int tn = sidx + 3 < nt ? t + 3 : tb + nt - 1;
 #pragma unroll
                     for (int e = 0; e < 4; e++)
                         wb[(u + 3) & 3][e] = *reinterpret_cast<const float4 *>(wc + (size_t)g.wt[tn] * wtap + e * 4);
-                    const float4 *pa = xlane + (size_t)tg.toff[t + 1 < 27 ? t + 1 : 26] * (XS / 4);
+                    const float4 *pa = xlane + (size_t)tg.toff[sidx + 1 < nt ? t + 1 : tb + nt - 1] * (XS / 4);
 #pragma unroll
                     for (int e = 0; e < 4; e++) af[(u + 1) & 1][e] = pa[e];
 #pragma unroll
@@ -582,6 +626,20 @@ __global__ __launch_bounds__(256, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
                 }
             }
         }
+    }
+    // waves 4..7 hand their tap half over through LDS (the halo is dead now)
+    __syncthreads();
+    if (tap_half) {
+        float *xo = Xs + (size_t)(wave & 3) * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) xo[r * 64] = acc[r];
+    }
+    __syncthreads();
+    if (tap_half) return;
+    {
+        const float *xi = Xs + (size_t)wave * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] += xi[r * 64];
     }
     const int od = od0 + dl;
     if (od >= g.Do) return;
@@ -621,7 +679,7 @@ static int launch_fwd32s(const FwdGeom &g, const float *a1, const float *a2, con
     }
     tg.EH = E[1]; tg.EW = E[2];
     tg.nslots = E[0] * E[1] * E[2];
-    if (tg.nslots > SXR * 32) return -1;
+    if (tg.nslots > SXR * 64 || g.ntaps != 27) return -1;
     int m = (1 << 16) / tg.EW + 1;
     for (int nn = 0; nn < tg.EH * tg.EW; nn++)
         if (((nn * m) >> 16) != nn / tg.EW) return -1;
@@ -647,7 +705,7 @@ static int launch_fwd32s(const FwdGeom &g, const float *a1, const float *a2, con
         cfgd = true;
     }
     const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_fwd32s, dim3(grid), dim3(256), lds, s, g, tg, a1, a2, w, bias, y1, y2);
+    hipLaunchKernelGGL(k_fwd32s, dim3(grid), dim3(512), lds, s, g, tg, a1, a2, w, bias, y1, y2);
     return check_launch("conv fwd (stride 2, CK=32)");
 }
 

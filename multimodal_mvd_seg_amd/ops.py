@@ -173,6 +173,8 @@ def _packed(weight, transposed, want_uf=False, want_ub=False):
         e.uf = e.ub = None
         e.stamp = None
         weight._mvd_pack = e
+        if len(_PACK_LIVE) >= 4096:  # inference-only use never calls repack_all: drop dead references here
+            _PACK_LIVE[:] = [r for r in _PACK_LIVE if r() is not None]
         _PACK_LIVE.append(weakref.ref(weight))
         stale = True
     new_wino = False
