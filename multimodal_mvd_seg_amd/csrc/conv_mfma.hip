@@ -928,18 +928,22 @@ struct WgTile {
     int dbg;
 };
 
-// NA / NB: float4 per thread of the A halo / B tile (LDS regions are NA*4 KiB and NB*4 KiB).  The NEXT tile's A and B
-// are prefetched into registers while the current tile's MFMAs run.
+// NA / NB: float4 per thread of the A halo / B tile (512 threads: LDS regions are NA*8 KiB and NB*8 KiB).  The NEXT
+// tile's A and B are prefetched into registers while the current tile's MFMAs run.
+// Eight waves = two groups of four on the SAME staged tile: wave & 3 picks the taps, group wave >> 2 takes every other
+// pair of k-steps and writes its own split-K partial (split * 2 + group) -- two waves per SIMD cover each other's LDS
+// round trips and the tile is staged once for twice the MFMAs.
 // SH: 1 = every tap reads the same B slot (3x3x3 conv: B = dy), 2 = the same A slot (transposed conv), 0 = neither
 template <int TPW, int NA, int NB, int SH>
-__global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+__global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
                                                        const float *__restrict__ a2, const float *__restrict__ b,
                                                        float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;
-    float *Bs = lds + (size_t)NA * 1024;
+    float *Bs = lds + (size_t)NA * 2048;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;
     const int i = lane & 31, h = lane >> 5;
     const int cb = blockIdx.y / tg.nkb, kb = blockIdx.y % tg.nkb;
     const int split = blockIdx.x;
@@ -992,7 +996,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
             const int z0 = od0 * g.sa[0] + tg.minA[0], y0 = oh0 * g.sa[1] + tg.minA[1], x0 = ow0 * g.sa[2] + tg.minA[2];
 #pragma unroll
             for (int u = 0; u < NA; u++) {
-                const int idx = u * 256 + tid;
+                const int idx = u * 512 + tid;
                 const int slot = idx >> 3;
                 const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
                 const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
@@ -1008,7 +1012,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
             const int z0 = od0 * g.sb[0] + tg.minB[0], y0 = oh0 * g.sb[1] + tg.minB[1], x0 = ow0 * g.sb[2] + tg.minB[2];
 #pragma unroll
             for (int u = 0; u < NB; u++) {
-                const int idx = u * 256 + tid;
+                const int idx = u * 512 + tid;
                 const int slot = idx >> 3;
                 const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
                 const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
@@ -1021,11 +1025,11 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
             }
         }
     };
-    auto store_tile = [&]() {  // unconditional: the LDS regions hold NA*256 / NB*256 float4
+    auto store_tile = [&]() {  // unconditional: the LDS regions hold NA*512 / NB*512 float4
 #pragma unroll
-        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 256 + tid) * 4) = ra[u];
+        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 512 + tid) * 4) = ra[u];
 #pragma unroll
-        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 256 + tid) * 4) = rb[u];
+        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 512 + tid) * 4) = rb[u];
     };
     // operands of k-step s2 (k = voxel pair).  Byte offsets: slot*128 + lane column; the per-tap part is hoisted.
     // The lane half h is the second voxel of the pair: s2 is even and TW a power of two >= 2, so (s2 + h) only changes
@@ -1078,14 +1082,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
         // eats a full LDS round trip)
         if (!(tg.dbg & 2)) {
             float a0[NAV], b0[NBV], a1_[NAV], b1_[NBV];
-            read_ops(0, a0, b0);
+            read_ops(2 * grp, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            for (int s2 = 0; s2 < TV; s2 += 4) {  // TV is a multiple of 4 for every tile shape
-                read_ops(s2 + 2, a1_, b1_);
+            for (int s2 = 2 * grp; s2 < TV; s2 += 8) {  // TV is a multiple of 8 for every tile shape; group: steps 2g + 4m
+                read_ops(s2 + 4, a1_, b1_);
                 mfmas(a0, b0);
                 interleave();
                 __builtin_amdgcn_sched_barrier(0);
-                read_ops(s2 + 4, a0, b0);
+                read_ops(s2 + 8, a0, b0);
                 mfmas(a1_, b1_);
                 interleave();
                 __builtin_amdgcn_sched_barrier(0);
@@ -1098,7 +1102,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_mfma(const WgradGeom g, const 
     for (int j = 0; j < TPW; j++) {
         const int t = wave + 4 * j;
         if (t < g.ntaps) {
-            float *po = partial + ((size_t)split * g.ntaps + t) * C * K;
+            float *po = partial + ((size_t)(split * 2 + grp) * g.ntaps + t) * C * K;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -2090,8 +2094,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         if (bf16_in) {  // k_wgrad16: 64 slots per uint4-per-thread; (NA, NB) = (7, 2) or (1, 8)
             if (nA <= 7 * 64 && nB <= 2 * 64) c = 0;
             else if (nA <= 1 * 64 && nB <= 8 * 64) c = 1;
-        } else if (nA * 8 <= 13 * 256 && nB * 8 <= 4 * 256) c = 0;
-        else if (nA * 8 <= 2 * 256 && nB * 8 <= 16 * 256) c = 1;
+        } else if (nA * 8 <= 13 * 256 && nB * 8 <= 4 * 256) c = 0;   // k_wgrad_mfma<.., 7, 2, ..>: 7 x 512 / 2 x 512 float4
+        else if (nA * 8 <= 2 * 256 && nB * 8 <= 16 * 256) c = 1;      // k_wgrad_mfma<.., 1, 8, ..>
         if (c < 0) continue;
         cfg = c;
         tg.TD = T3[0]; tg.TH = T3[1]; tg.TW = T3[2];
@@ -2147,7 +2151,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
 #define WG_LAUNCH(TPW, NA, NB, SH)                                                                                   \
     {                                                                                                              \
         auto kern = k_wgrad_mfma<TPW, NA, NB, SH>;                                                                 \
-        const size_t lds = (size_t)(NA + NB) * 4096;                                                               \
+        const size_t lds = (size_t)(NA + NB) * 8192;                                                               \
         static bool cfgd = false;                                                                                  \
         if (!cfgd) {                                                                                               \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -2157,7 +2161,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
             }                                                                                                      \
             cfgd = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tg, a1, a2, b, partial);                              \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, g, tg, a1, a2, b, partial);                              \
     }
     bool sameA = true, sameB = true;
     for (int t = 1; t < g.ntaps; t++) {
@@ -2269,18 +2273,23 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         else if (tpw <= 4) WG_LAUNCH(4, NA, NB, SH) \
         else WG_LAUNCH(7, NA, NB, SH)          \
     }
+    // the generic kernel runs two wave groups per workgroup, each with its own split-K partial
+    if ((size_t)2 * tg.nsplit * g.ntaps * C * g.K * sizeof(float) > ws_bytes) {
+        set_error("conv wgrad (mfma): workspace too small for two partials per split");
+        return 1;
+    }
     if (cfg == 0) {
-        if (sameB) WG_TPW(13, 4, 1)
-        else WG_TPW(13, 4, 0)
+        if (sameB) WG_TPW(7, 2, 1)
+        else WG_TPW(7, 2, 0)
     } else {
-        if (sameA) WG_TPW(2, 16, 2)
-        else WG_TPW(2, 16, 0)
+        if (sameA) WG_TPW(1, 8, 2)
+        else WG_TPW(1, 8, 0)
     }
 #undef WG_TPW
 #undef WG_LAUNCH
     if (check_launch("conv wgrad (mfma)")) return 1;
     const long per = (long)g.ntaps * C * g.K;
-    hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
+    hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per, 64)), dim3(256), 0, s, g, partial, dw, 2 * tg.nsplit);
     return check_launch("conv wgrad reduce (mfma)");
 }
 
