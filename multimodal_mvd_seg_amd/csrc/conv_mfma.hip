@@ -723,7 +723,7 @@ static int num_cus() {
 static int split_for(const void *ws, size_t ws_bytes, long wgs, int nch, size_t out_elems, int nkb) {
     int S = 1;
     if (ws && wgs < 256 && nch >= 4) {
-        long want = (512 + wgs - 1) / wgs;
+        long want = 512 / wgs;  // two workgroups per CU resident: never spill into a second, mostly empty round
         if (want > MAX_SPLIT) want = MAX_SPLIT;
         if (want > nch / 2) want = nch / 2;
         while (want > 1 && (size_t)want * out_elems * sizeof(float) > ws_bytes) want--;
@@ -819,7 +819,12 @@ int fwd_mfma(const FwdGeom &g, const float *a1, const float *a2, const float *w,
     if (LCK == 32 && unit_stride && !(dbg & 4)) {
         // ---- CK = 32 kernel: 4x8x8 tile (one workgroup per CU) or 4x4x8 tile (two per CU)
         // a 64-wide N tile may span the two output pointers: each 32-wide half lies in one of them (K1 % 32 == 0)
-        const int NT = (K % 64 == 0) ? 2 : 1;
+        static int nt_rule = -1;  // MVD_CONV_NT: 0 = 64-wide N tile whenever K % 64 == 0, 1 (default) = narrow tile for skinny problems
+        if (nt_rule < 0) nt_rule = getenv("MVD_CONV_NT") ? atoi(getenv("MVD_CONV_NT")) : 1;
+        // skinny problems (8^3 / 4^3 stages): fewer than one workgroup per CU even with the channel split -- the 32-wide N
+        // tile doubles the workgroup count and halves the serial MFMA chain of each
+        const long wg64 = (long)g.N * ((g.Do + 3) / 4) * ((g.Ho + 3) / 4) * ((g.Wo + 7) / 8) * (K / 64);
+        const int NT = (K % 64 == 0 && !(nt_rule == 1 && wg64 < 128)) ? 2 : 1;
         static int force_mt = -1;
         if (force_mt < 0) force_mt = getenv("MVD_CONV_MT") ? atoi(getenv("MVD_CONV_MT")) : 0;
         static int force_tg = -1;
