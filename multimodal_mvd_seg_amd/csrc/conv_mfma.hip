@@ -942,7 +942,7 @@ struct WgTile {
 template <int TPW, int NA, int NB, int SH>
 __global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
                                                        const float *__restrict__ a2, const float *__restrict__ b,
-                                                       float *__restrict__ partial) {
+                                                       float *__restrict__ partial, float *__restrict__ pbias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;
     float *Bs = lds + (size_t)NA * 2048;
@@ -1058,10 +1058,15 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const 
 #pragma unroll
         for (int j = 0; j < NBV; j++) bv[j] = *reinterpret_cast<const float *>(Bb + sb_ + boff[j]);
     };
+    // bias gradient (SH == 1: every tap reads the same dy slot): the tap-group-0 wave of the c-block-0 workgroups sees
+    // every dy value of its k-block exactly once per (split, group) -- per-lane sums, reduced by k_dbias_reduce
+    const bool dob = SH == 1 && pbias != nullptr && cb == 0 && wave == 0;
+    float bsum = 0.f;
     auto mfmas = [&](const float (&av)[NAV], const float (&bv)[NBV]) {
 #pragma unroll
         for (int j = 0; j < TPW; j++)
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[SH == 2 ? 0 : j], bv[SH == 1 ? 0 : j], acc[j], 0, 0, 0);
+        if (SH == 1 && dob) bsum += bv[0];
     };
     // scheduling hint for one (reads of the next step | MFMAs of this step) block: one MFMA, then a few of the
     // next step's LDS reads / address VALU ops under its shadow
@@ -1102,6 +1107,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const 
         }
         tile = next;
     }
+    if (SH == 1 && dob && i < kvalid) pbias[((size_t)(split * 2 + grp) * 2 + h) * K + k0 + i] = bsum;
     // partial[split][t][c][k]; D layout: col = lane&31 -> k, row -> c
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
@@ -2062,7 +2068,8 @@ static bool wgrad_mfma_ok(const WgradGeom &g) {
 
 size_t wgrad_mfma_ws(const WgradGeom &g) {
     if (!wgrad_mfma_ok(g)) return 0;
-    return (size_t)wgrad_max_split(g) * g.ntaps * (g.C1 + g.C2) * g.K * sizeof(float) + 256;
+    // split-K partials + the bias-gradient rows (two lane halves per partial)
+    return (size_t)wgrad_max_split(g) * (g.ntaps * (size_t)(g.C1 + g.C2) + 2) * g.K * sizeof(float) + 256;
 }
 
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
@@ -2166,7 +2173,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
             }                                                                                                      \
             cfgd = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, g, tg, a1, a2, b, partial);                              \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, g, tg, a1, a2, b, partial, (SH) == 1 ? pbias_g : nullptr); \
     }
     bool sameA = true, sameB = true;
     for (int t = 1; t < g.ntaps; t++) {
@@ -2283,6 +2290,11 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         set_error("conv wgrad (mfma): workspace too small for two partials per split");
         return 1;
     }
+    // bias gradient inside the kernel when every tap reads the same dy slot and the rows fit behind the partials
+    const size_t need_g = (size_t)2 * tg.nsplit * g.ntaps * C * g.K * sizeof(float);
+    float *pbias_g = nullptr;
+    if (dbias && dbias_done && cfg == 0 && sameB && need_g + (size_t)4 * tg.nsplit * g.K * sizeof(float) <= ws_bytes)
+        pbias_g = partial + need_g / sizeof(float);
     if (cfg == 0) {
         if (sameB) WG_TPW(7, 2, 1)
         else WG_TPW(7, 2, 0)
@@ -2293,6 +2305,11 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
 #undef WG_TPW
 #undef WG_LAUNCH
     if (check_launch("conv wgrad (mfma)")) return 1;
+    if (pbias_g) {
+        hipLaunchKernelGGL(k_dbias_reduce, dim3(cdiv(g.K, 64)), dim3(1024), 0, s, pbias_g, dbias, g.K, tg.nsplit * 4);
+        if (check_launch("conv wgrad dbias reduce")) return 1;
+        *dbias_done = 1;
+    }
     const long per = (long)g.ntaps * C * g.K;
     hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per, 64)), dim3(256), 0, s, g, partial, dw, 2 * tg.nsplit);
     return check_launch("conv wgrad reduce (mfma)");
