@@ -876,3 +876,71 @@ def test_packed_weight_cache_follows_every_kind_of_update():
         close(y2, F.conv3d(x, w2, conv.bias, 1, 1).detach().cpu(), 2e-5, 1e-5, "fresh tensor")
     finally:
         call("mvd_set_wino_min_items", -1)
+
+
+@pytest.mark.gpu
+def test_trainer_fed_by_device_loader_learns_and_postprocesses():
+    """The widened rows together: DeviceDataLoader3D (8f-2) feeds nnUNetTrainerMI355.train_step (the hot path), the
+    trained net predicts through the sliding-window predictor (8f-1) and the result goes through the connected-component
+    post-processing (8f-3).  Synthetic task: label = which of two intensity blobs a voxel belongs to."""
+    from multimodal_mvd_seg_amd import trainer, inference, postprocessing as PP
+    from multimodal_mvd_seg_amd.dataloading import DeviceDataLoader3D
+    rng = np.random.default_rng(0)
+
+    class DS:
+        def __init__(self):
+            self.cases = {}
+            for i in range(4):
+                shp = (40, 44, 48)
+                zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shp], indexing="ij")
+                seg = np.zeros((1, *shp), dtype=np.int16)
+                c1 = rng.integers(10, 30, 3)
+                c2 = rng.integers(10, 30, 3)
+                seg[0][(zz - c1[0]) ** 2 + (yy - c1[1]) ** 2 + (xx - c1[2]) ** 2 < 64] = 1
+                seg[0][(zz - c2[0] - 8) ** 2 + (yy - c2[1] - 8) ** 2 + (xx - c2[2] - 12) ** 2 < 49] = 2
+                data = np.stack([(seg[0] == 1) * 1.0, (seg[0] == 2) * 1.0], 0).astype(np.float32)
+                data += 0.3 * rng.standard_normal(data.shape).astype(np.float32)
+                locs = {c: np.argwhere(seg == c) for c in (1, 2)}
+                self.cases[f"c{i}"] = (data, seg, {"class_locations": locs})
+
+        def keys(self):
+            return self.cases.keys()
+
+        def load_case(self, k):
+            return self.cases[k]
+
+    ds = DS()
+    patch = (32, 32, 32)
+    strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
+    plans = trainer.make_plans(patch, strides, batch_size=2, base_features=32, max_features=64)
+    dj = {"channel_names": {"0": "a", "1": "b"}, "labels": {"background": 0, "one": 1, "two": 2}}
+    torch.manual_seed(0)
+    tr = trainer.nnUNetTrainerMI355(plans, "3d_fullres", 0, dj, device=DEV)
+    tr.initialize()
+    tr.on_train_epoch_start()
+    dl = DeviceDataLoader3D(ds, tr.batch_size, patch, patch, tr.label_manager, oversample_foreground_percent=0.33,
+                            mirror_axes=(0, 1, 2), deep_supervision_scales=tr._get_deep_supervision_scales(), device=DEV)
+    np.random.seed(0)
+    losses = []
+    for _ in range(60):
+        b = next(dl)
+        assert b["data"].is_cuda and len(b["target"]) == len(tr._get_deep_supervision_scales())
+        losses.append(float(tr.train_step(b)["loss"]))
+    assert np.mean(losses[-10:]) < np.mean(losses[:5]) - 0.3, (losses[:5], losses[-10:])
+    # predict one whole case tile by tile, argmax, keep the two largest components of the foreground
+    tr.set_deep_supervision_enabled(False)
+    tr.network.eval()
+    data, seg, _ = ds.load_case("c0")
+    pred = inference.SlidingWindowPredictor(tr.network, patch, 3, tile_step_size=0.5, use_gaussian=True,
+                                            use_mirroring=False, device=DEV)
+    with torch.no_grad():
+        logits = pred.predict_sliding_window_return_logits(torch.from_numpy(data).to(DEV))
+    hard = logits.argmax(0).to(torch.int32)
+    fg = (hard > 0)
+    ref_fg = torch.from_numpy(seg[0] > 0).to(DEV)
+    dice = 2.0 * float((fg & ref_fg).sum()) / max(1.0, float(fg.sum() + ref_fg.sum()))
+    assert dice > 0.6, dice
+    cleaned = PP.remove_all_but_largest_component_from_segmentation(hard, [1, 2], 0)
+    from multimodal_mvd_seg_amd import ops
+    _, count = ops.cc_label(ops.seg_label_mask(cleaned, [1, 2]), 26)
+    assert int(count.item()) <= 2 and bool(((cleaned == hard) | (cleaned == 0)).all())
