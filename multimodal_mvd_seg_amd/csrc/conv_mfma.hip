@@ -1354,7 +1354,9 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_wino(const WgradGeom g, const 
 // B0 / NBW: the wave owns position columns b = B0 .. B0+NBW-1 (NBW = 4: four waves per workgroup, one per position row;
 // NBW = 2: eight waves, two per row -- half the accumulators per wave, so two waves share a SIMD and cover each
 // other's barrier / LDS waits).  TPB = threads per workgroup (staging loops).
-template <int A, int B0, int NBW, int TPB, int NA, int NB>
+// GZ0 / NGZ: the wave owns filter planes GZ0 .. GZ0+NGZ-1 (3 planes by default; the twelve-wave variant gives each wave
+// one plane and all four columns: 64 accumulator registers, three waves per SIMD).
+template <int A, int B0, int NBW, int TPB, int NA, int NB, int GZ0 = 0, int NGZ = 3>
 __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTile &tg, const float *__restrict__ a1,
                                                  const float *__restrict__ a2, const float *__restrict__ b,
                                                  float *__restrict__ partial, float *__restrict__ pbias, float *As,
@@ -1368,8 +1370,8 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     const int split = blockIdx.x;
     const int C = g.C1 + g.C2, K = g.K;
 
-    constexpr int NTL = 3 * NBW;
-    f32x16 acc[NTL];  // [gz][b - B0]
+    constexpr int NTL = NGZ * NBW;
+    f32x16 acc[NTL];  // [gz - GZ0][b - B0]
 #pragma unroll
     for (int j = 0; j < NTL; j++)
 #pragma unroll
@@ -1486,12 +1488,12 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
         E[0] = f0; E[1] = f0 + f1; E[2] = f0 - f1; E[3] = -f1;
     };
 
-    float R[3][4];      // [gz][column ring: halo column x lives in slot x & 3]
-    float V[2][3][4];   // MFMA A operands, double buffered over the step parity
+    float R[NGZ][4];      // [gz - GZ0][column ring: halo column x lives in slot x & 3]
+    float V[2][NGZ][4];   // MFMA A operands, double buffered over the step parity
     float E[2][4];      // MFMA B operands
     // bias gradient: wave 0 of the c-block-0 workgroups sees every dy value of its k-block exactly once (the 2x2
     // quads it fetches for E): per-lane partial sums, reduced over lanes halves / splits by k_dbias_reduce
-    const float bflag = (A == 0 && B0 == 0 && pbias != nullptr && cb == 0) ? 1.f : 0.f;
+    const float bflag = (A == 0 && B0 == 0 && GZ0 == 0 && pbias != nullptr && cb == 0) ? 1.f : 0.f;
     float bsum = 0.f;
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
@@ -1506,17 +1508,17 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
             float e[4];
             fetch_e(0, 0, e);
 #pragma unroll
-            for (int gz = 0; gz < 3; gz++)
+            for (int gz = 0; gz < NGZ; gz++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     float pa, pb;
-                    fetch_col(gz, 0, c, pa, pb);
+                    fetch_col(GZ0 + gz, 0, c, pa, pb);
                     R[gz][c] = rcomb(pa, pb);
                 }
             make_E(e, E[0]);
-            if (A == 0 && B0 == 0) bsum += bflag * ((e[0] + e[1]) + (e[2] + e[3]));
+            if (A == 0 && B0 == 0 && GZ0 == 0) bsum += bflag * ((e[0] + e[1]) + (e[2] + e[3]));
 #pragma unroll
-            for (int gz = 0; gz < 3; gz++) {
+            for (int gz = 0; gz < NGZ; gz++) {
                 V[0][gz][0] = R[gz][0] - R[gz][2];
                 V[0][gz][1] = R[gz][1] + R[gz][2];
                 V[0][gz][2] = R[gz][2] - R[gz][1];
@@ -1535,7 +1537,7 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                 // (columns 0..3) of quad row hq + 1 (the tile's very last step re-reads row hq: unused)
                 const int nhq = wq == 3 ? (hq < 3 ? hq + 1 : hq) : hq;
                 constexpr int NC = 4;  // columns fetched at a row end; 2 otherwise
-                float pa[3][NC], pb[3][NC], e[4];
+                float pa[NGZ][NC], pb[NGZ][NC], e[4];
 #pragma unroll
                 for (int j = 0; j < NTL; j++) {
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[cur][j / NBW][B0 + j % NBW], E[cur][B0 + j % NBW], acc[j], 0, 0,
@@ -1545,27 +1547,27 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                     // each) at a row end; with 6 MFMAs per step the row-end groups start at slot 0
                     const int fg = (NTL >= 7 || wq != 3) ? j - 1 : j;
                     if (wq != 3) {
-                        if (fg >= 0 && fg < 3) {  // plane fg: two new columns
-                            fetch_col(fg, nhq, 2 * wq + 4, pa[fg][0], pb[fg][0]);
-                            fetch_col(fg, nhq, 2 * wq + 5, pa[fg][1], pb[fg][1]);
+                        if (fg >= 0 && fg < NGZ) {  // plane fg: two new columns
+                            fetch_col(GZ0 + fg, nhq, 2 * wq + 4, pa[fg][0], pb[fg][0]);
+                            fetch_col(GZ0 + fg, nhq, 2 * wq + 5, pa[fg][1], pb[fg][1]);
                         }
                     } else {
-                        if (fg >= 0 && fg < 6) {  // plane fg/2: four columns, two per slot
+                        if (fg >= 0 && fg < 2 * NGZ) {  // plane fg/2: four columns, two per slot
                             const int gz = fg >> 1, c2 = (fg & 1) * 2;
-                            fetch_col(gz, nhq, c2, pa[gz][c2], pb[gz][c2]);
-                            fetch_col(gz, nhq, c2 + 1, pa[gz][c2 + 1], pb[gz][c2 + 1]);
+                            fetch_col(GZ0 + gz, nhq, c2, pa[gz][c2], pb[gz][c2]);
+                            fetch_col(GZ0 + gz, nhq, c2 + 1, pa[gz][c2 + 1], pb[gz][c2 + 1]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // window update + operands of the next step (VALU only; the MFMAs above read V[cur] / E[cur])
                 make_E(e, E[nxt]);
-                if (A == 0 && B0 == 0) {  // the tile's very last fetch is a re-read: not counted
+                if (A == 0 && B0 == 0 && GZ0 == 0) {  // the tile's very last fetch is a re-read: not counted
                     const float fl = (wq == 3 && hq == 3) ? 0.f : bflag;
                     bsum += fl * ((e[0] + e[1]) + (e[2] + e[3]));
                 }
 #pragma unroll
-                for (int gz = 0; gz < 3; gz++) {
+                for (int gz = 0; gz < NGZ; gz++) {
                     if (wq != 3) {
                         R[gz][(2 * wq + 4) & 3] = rcomb(pa[gz][0], pb[gz][0]);
                         R[gz][(2 * wq + 5) & 3] = rcomb(pa[gz][1], pb[gz][1]);
@@ -1591,14 +1593,14 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     // partial[split][gz][a][b][c][k]; D layout: col = lane&31 -> k, row -> c
 #pragma unroll
     for (int j = 0; j < NTL; j++) {
-        float *po = partial + ((((size_t)split * 3 + j / NBW) * 4 + A) * 4 + B0 + j % NBW) * C * K;
+        float *po = partial + ((((size_t)split * 3 + GZ0 + j / NBW) * 4 + A) * 4 + B0 + j % NBW) * C * K;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
         }
     }
-    if (A == 0 && B0 == 0 && pbias != nullptr && cb == 0) pbias[((size_t)split * 2 + h) * K + k0 + i] = bsum;
+    if (A == 0 && B0 == 0 && GZ0 == 0 && pbias != nullptr && cb == 0) pbias[((size_t)split * 2 + h) * K + k0 + i] = bsum;
 }
 
 // dbias[k] = sum over splits and lane halves of pbias[row][k]   (fp64, fixed order).  Block = 64 channels x 16 row
@@ -1658,6 +1660,34 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_wino2w8(const WgradGeom g, con
         default: MVD_W8(3, 2); break;
     }
 #undef MVD_W8
+}
+
+// twelve-wave variant: wave w owns position row w & 3 and filter plane w >> 2 with all four columns (4 accumulator tiles):
+// three waves per SIMD; NA12 / NB12 = float4 per thread of the same LDS tiles staged by 768 threads
+template <int NA12, int NB12>
+__global__ __launch_bounds__(768, 1) void k_wgrad_wino2w12(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
+                                                           const float *__restrict__ a2, const float *__restrict__ b,
+                                                           float *__restrict__ partial, float *__restrict__ pbias) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;
+    float *Bs = lds + (size_t)NA12 * 3072;  // A region: NA12 float4 per thread x 768 threads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#define MVD_W12(AA, GZ) wgrad_wino2_body<AA, 0, 4, 768, NA12, NB12, GZ, 1>(g, tg, a1, a2, b, partial, pbias, As, Bs)
+    switch (wave) {
+        case 0: MVD_W12(0, 0); break;
+        case 1: MVD_W12(1, 0); break;
+        case 2: MVD_W12(2, 0); break;
+        case 3: MVD_W12(3, 0); break;
+        case 4: MVD_W12(0, 1); break;
+        case 5: MVD_W12(1, 1); break;
+        case 6: MVD_W12(2, 1); break;
+        case 7: MVD_W12(3, 1); break;
+        case 8: MVD_W12(0, 2); break;
+        case 9: MVD_W12(1, 2); break;
+        case 10: MVD_W12(2, 2); break;
+        default: MVD_W12(3, 2); break;
+    }
+#undef MVD_W12
 }
 
 // dw[k][c][gz][i][j] = sum_{a,b} G[a][i] G[b][j] (sum_split M[split][gz][a][b][c][k])   (fp64, fixed order)
@@ -2223,8 +2253,9 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
             if (wino_mode() == 2 && tg.TH == 8 && tg.TW == 8 && tg.EAh == 10 && tg.EAw == 10 && tg.EBh == 8 && tg.EBw == 8 &&
                 need_w2 <= ws_bytes) {
                 float *pbias = (dbias && dbias_done) ? partial + need_m2 / sizeof(float) : nullptr;
-                static const int w8 = getenv("MVD_WGRAD_W8") ? atoi(getenv("MVD_WGRAD_W8")) : 1;
-                auto kern2 = w8 ? k_wgrad_wino2w8<7, 2> : k_wgrad_wino2<13, 4>;
+                // MVD_WGRAD_W8: 12 (default) = twelve waves (one plane per wave, 3 per SIMD), 1 = eight waves, 0 = four waves
+                static const int w8 = getenv("MVD_WGRAD_W8") ? atoi(getenv("MVD_WGRAD_W8")) : 12;
+                auto kern2 = w8 == 12 ? k_wgrad_wino2w12<5, 2> : (w8 ? k_wgrad_wino2w8<7, 2> : k_wgrad_wino2<13, 4>);
                 static bool cfgd_w2 = false;
                 if (!cfgd_w2) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2234,8 +2265,9 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                     }
                     cfgd_w2 = true;
                 }
-                hipLaunchKernelGGL(kern2, grid, dim3(w8 ? 512 : 256), w8 ? (size_t)(7 + 2) * 8192 : (size_t)(13 + 4) * 4096, s, g, tg,
-                                   a1, a2, b, partial, pbias);
+                hipLaunchKernelGGL(kern2, grid, dim3(w8 == 12 ? 768 : (w8 ? 512 : 256)),
+                                   w8 == 12 ? (size_t)(5 + 2) * 12288 : (w8 ? (size_t)(7 + 2) * 8192 : (size_t)(13 + 4) * 4096), s, g,
+                                   tg, a1, a2, b, partial, pbias);
                 if (check_launch("conv wgrad (winograd 2-D)")) return 1;
                 if (pbias) {
                     hipLaunchKernelGGL(k_dbias_reduce, dim3(cdiv(g.K, 64)), dim3(1024), 0, s, pbias, dbias, g.K, tg.nsplit * 2);
