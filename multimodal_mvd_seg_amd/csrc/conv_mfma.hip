@@ -32,6 +32,50 @@ struct FwdTile {
 
 // L32: the packed weights use the CK = 32 layout (C % 32 == 0) but this kernel still walks 8-channel sub-chunks
 // {sc*4..sc*4+3} u {16+sc*4..16+sc*4+3} of each 32-chunk (used for the wide-halo stride-2 geometries only).
+// Epilogue of the gather kernels: stores one 32 x 32 accumulator tile whose rows are a 4 (h) x 8 (w) voxel patch of output
+// plane od.  Accumulator row r of lane half hh is voxel (r >> 2, (r & 3) + 4 * hh): everything but the 4 * hh shift along W
+// is wave-uniform, so the voxel offset is scalar arithmetic and a lane adds one 64-bit pointer (the per-row index chain
+// of 64-bit multiplies used to cost ~25 VALU instructions per stored value = more than the MFMAs of a few-tap tile).
+__device__ __forceinline__ void store_tile32(const FwdGeom &g, const f32x16 &acc, float bv, int n, int od, int ohb, int ow0,
+                                             int k, int hh, int S, int split, int Ktot, float *__restrict__ part,
+                                             float *__restrict__ y1, float *__restrict__ y2) {
+    const int owl = ow0 + 4 * hh;
+    if (S > 1) {  // raw partial, indexed by the iteration voxel: part[split][n][o][K]
+        float *pl = part + (size_t)(4 * hh) * Ktot + k;
+        const size_t nb = ((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int oh = ohb + (r >> 2), owu = ow0 + (r & 3);
+            const size_t uo = (nb + ((size_t)od * g.Ho + oh) * g.Wo + owu) * Ktot;
+            if (oh < g.Ho && owl + (r & 3) < g.Wo) pl[uo] = acc[r];
+        }
+    } else if (g.K2 == 0 || g.K1 == g.K2) {
+        const int Ks = g.K1;
+        float *yl = (k < g.K1 ? y1 + k : y2 + (k - g.K1)) + (size_t)(4 * hh * g.so[2]) * Ks;
+        const size_t pb = ((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int oh = ohb + (r >> 2), owu = ow0 + (r & 3);
+            const size_t uo = ((pb + (oh * g.so[1] + g.oo[1])) * g.Wy + (owu * g.so[2] + g.oo[2])) * Ks;
+            if (oh < g.Ho && owl + (r & 3) < g.Wo) yl[uo] = acc[r] + bv;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int oh = ohb + (r >> 2), ow = owl + (r & 3);
+            if (oh < g.Ho && ow < g.Wo) {
+                const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
+                                  (ow * g.so[2] + g.oo[2]);
+                const float val = acc[r] + bv;
+                if (k < g.K1)
+                    y1[ov * g.K1 + k] = val;
+                else
+                    y2[ov * g.K2 + (k - g.K1)] = val;
+            }
+        }
+    }
+}
+
 template <int CK, int NT, int MT, bool L32>
 __global__ __launch_bounds__(256, 2) void k_fwd_mfma(const FwdGeom g, const FwdTile tg, const float *__restrict__ a1,
                                                      const float *__restrict__ a2, const float *__restrict__ w,
@@ -191,25 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_mfma(const FwdGeom g, const FwdT
         for (int q_ = 0; q_ < NT; q_++) {
             const int k = kb * KT + q_ * 32 + i;
             const float bv = (bias && S == 1) ? bias[k] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int oh = oh0 + 4 * m + (row >> 3), ow = ow0 + (row & 7);
-                if (oh < g.Ho && ow < g.Wo) {
-                    if (S > 1) {  // raw partial, indexed by the iteration voxel: part[split][n][o][K]
-                        const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
-                        part[(((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k] = acc[m][q_][r];
-                        continue;
-                    }
-                    const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
-                                      (ow * g.so[2] + g.oo[2]);
-                    const float val = acc[m][q_][r] + bv;
-                    if (k < g.K1)
-                        y1[ov * g.K1 + k] = val;
-                    else
-                        y2[ov * g.K2 + (k - g.K1)] = val;
-                }
-            }
+            store_tile32(g, acc[m][q_], bv, n, od, oh0 + 4 * m, ow0, k, h, S, split, tg.K, part, y1, y2);
         }
 }
 
@@ -436,25 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
         for (int q = 0; q < NT; q++) {
             const int k = kb * KT + q * 32 + i;
             const float bv = (bias && tg.S == 1) ? bias[k] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int oh = oh0 + 4 * m + (row >> 3), ow = ow0 + (row & 7);
-                if (oh < g.Ho && ow < g.Wo) {
-                    if (tg.S > 1) {
-                        const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
-                        part[(((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k] = acc[m][q][r];
-                    } else {
-                        const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
-                                          (ow * g.so[2] + g.oo[2]);
-                        const float val = acc[m][q][r] + bv;
-                        if (k < g.K1)
-                            y1[ov * g.K1 + k] = val;
-                        else
-                            y2[ov * g.K2 + (k - g.K1)] = val;
-                    }
-                }
-            }
+            store_tile32(g, acc[m][q], bv, n, od, oh0 + 4 * m, ow0, k, h, tg.S, split, tg.K, part, y1, y2);
         }
 }
 
