@@ -247,6 +247,19 @@ def pack_weight_bf16(weight, transposed):
     return wf, wb
 
 
+def _packed_bf16(weight, transposed):
+    """bf16 packs cached on the weight tensor under the same (epoch, version) stamp as the fp32 ones: inference packs
+    once; in training the optimizer step makes them stale and the next forward re-packs them per layer."""
+    w = weight.detach()
+    if not w.is_contiguous():
+        return pack_weight_bf16(weight, transposed)
+    e = getattr(weight, "_mvd_pack16", None)
+    if e is None or e[0] != (_pack_stamp(w), transposed, w.device):
+        e = ((_pack_stamp(w), transposed, w.device),) + tuple(pack_weight_bf16(weight, transposed))
+        weight._mvd_pack16 = e
+    return e[1], e[2]
+
+
 def _out_dim(i, k, s):
     return (i + 2 * ((k - 1) // 2) - k) // s + 1
 
@@ -277,7 +290,7 @@ class Conv3dFn(Function):
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, od[0] * od[1] * od[2], K), x1.device)
         ub = None
         if bf:
-            wf, wb = pack_weight_bf16(weight, False)
+            wf, wb = _packed_bf16(weight, False)
             call("mvd_conv3d_fwd_bf16", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
                  _p(ws), ws.numel(), _stream())
         else:
@@ -361,7 +374,7 @@ class ConvTranspose3dFn(Function):
             raise RuntimeError("convT3d: channel mismatch")
         bf = _is_bf16(x)
         if bf:
-            wf, wb = pack_weight_bf16(weight, True)
+            wf, wb = _packed_bf16(weight, True)
         else:
             pk = _packed(weight, True)
             wf, wb = pk.wf, pk.wb
