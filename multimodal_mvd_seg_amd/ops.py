@@ -141,7 +141,8 @@ class _PackEntry:
 
 
 def _pack_stamp(w):
-    return (_PACK_EPOCH[0], w._version)
+    # data_ptr: `p.data = other` swaps the storage without a version bump on the parameter object
+    return (_PACK_EPOCH[0], w._version, w.data_ptr())
 
 
 def _packed(weight, transposed, want_uf=False, want_ub=False):
