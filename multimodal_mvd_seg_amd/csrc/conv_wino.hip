@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             const int od = od0 + (r & 3), oh = oh0 + 2 * (r >> 3) + yr;   // wave-uniform
             const int owu = ow0 + yc + 4 * ((r >> 2) & 1);                // wave-uniform part of ow
             const size_t uo = ((((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + owu) * Ks;
-            if (od < g.Do && oh < g.Ho && (((r >> 2) & 1) ? okw1 : okw0)) {
+            if (od < g.Do && oh < g.Ho && (((r >> 2) & 1) ? okw1 : okw0) && !(kAblate && (tg.dbg & 8) && val != 12345.f)) {
                 ylane[uo] = val;
                 ssum += val;
                 ssq += val * val;
