@@ -76,6 +76,89 @@ __global__ void k_seghead_dx(const float *__restrict__ dl, const float *__restri
     }
 }
 
+// C % 4 == 0 fast paths (HBM-bound: the tiled kernels above ran at 2-3 TB/s on the 128^3 head).
+// fwd: one thread per voxel, the C channels as C/4 16-byte loads all in flight, weights as scalar operands; the
+// accumulation order per class is the channel order of k_seghead_fwd (same result).  Planar logits: coalesced stores.
+template <bool XB>
+__global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, float *__restrict__ logits, long V,
+                                                         int C, int K) {
+    const int n = blockIdx.y;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) acc[k] = 0.f;
+    const size_t xo = ((size_t)n * V + v) * C;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        float4 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) q[j] = (c0 + 4 * j < C) ? ld4<XB>(x, xo + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                const float *wk = w + (size_t)k * C + c0;  // wave-uniform: scalar loads
+                float a = acc[k];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (c0 + 4 * j < C) {
+                        a += q[j].x * wk[4 * j];
+                        a += q[j].y * wk[4 * j + 1];
+                        a += q[j].z * wk[4 * j + 2];
+                        a += q[j].w * wk[4 * j + 3];
+                    }
+                acc[k] = a;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) logits[((size_t)n * K + k) * V + v] = acc[k] + bias[k];
+}
+
+// dx: one thread per (quad of 4 consecutive voxels, 4-channel group): the K class gradients of the quad come in as one
+// float4 per class (planar dl), the thread's K x 4 weights stay in registers over its grid-stride loop, and the C/4 lanes
+// of a voxel write one full 128-byte line.  k order as in k_seghead_dx.  V % 4 == 0.
+template <bool XB>
+__global__ __launch_bounds__(256) void k_seghead_dx4(const float *__restrict__ dl, const float *__restrict__ w,
+                                                     float *__restrict__ dx, long V, int C, int K, int accumulate) {
+    const int n = blockIdx.y;
+    const int CG = C >> 2;
+    const int g = threadIdx.x % CG, r = threadIdx.x / CG, R = 256 / CG;
+    if (r >= R) return;
+    float4 wk[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        wk[k] = k < K ? *reinterpret_cast<const float4 *>(w + (size_t)k * C + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long nq = V >> 2;
+    for (long q = (long)blockIdx.x * R + r; q < nq; q += (long)gridDim.x * R) {
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                const float4 d = *reinterpret_cast<const float4 *>(dl + ((size_t)n * K + k) * V + 4 * q);
+                const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    a[u].x += dv[u] * wk[k].x;
+                    a[u].y += dv[u] * wk[k].y;
+                    a[u].z += dv[u] * wk[k].z;
+                    a[u].w += dv[u] * wk[k].w;
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t o = ((size_t)n * V + 4 * q + u) * C + (size_t)g * 4;
+            if (accumulate) {
+                const float4 old = ld4<XB>(dx, o);
+                a[u].x += old.x; a[u].y += old.y; a[u].z += old.z; a[u].w += old.w;
+            }
+            st4<XB>(dx, o, a[u].x, a[u].y, a[u].z, a[u].w);
+        }
+    }
+}
+
 // partial[b][k*C + c] = sum over the block's voxels of dl[k][v]*x[v][c]; partial[b][K*C + k] = sum dl[k][v]
 template <bool XB>
 __global__ void k_seghead_dw(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
@@ -646,6 +729,11 @@ static int seghead_fwd_impl(const float *x, bool xb, const float *w, const float
                             int C, int K, void *stream) {
     MVD_REQUIRE(x && w && bias && logits, "seghead_fwd: null pointer");
     MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && K > 0 && K <= KMAX, "seghead_fwd: bad shape (K<=8)");
+    if (C % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
+        auto kv = xb ? k_seghead_fwd_vox<true> : k_seghead_fwd_vox<false>;
+        hipLaunchKernelGGL(kv, dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C, K);
+        return check_launch("seghead_fwd");
+    }
     auto kern = xb ? k_seghead_fwd<true> : k_seghead_fwd<false>;
     hipLaunchKernelGGL(kern, dim3(cdiv(V, 64), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C, K);
     return check_launch("seghead_fwd");
@@ -662,7 +750,7 @@ int mvd_seghead_fwd_bf16(const uint16_t *x, const float *w, const float *bias, f
 static long seghead_chunk(long total, int *nblk) {
     long nb = total / 2048;
     if (nb < 1) nb = 1;
-    if (nb > 1024) nb = 1024;
+    if (nb > 4096) nb = 4096;  // 16 workgroups per CU: the weight-gradient pass is a pure stream over x and dl
     long chunk = cdiv(total, nb);
     chunk = cdiv(chunk, 64) * 64;
     *nblk = (int)cdiv(total, chunk);
@@ -683,9 +771,17 @@ static int seghead_bwd_impl(const float *x, bool xb, const float *w, const float
     MVD_REQUIRE(ws_bytes >= mvd_seghead_bwd_workspace_bytes(N, V, C, K), "seghead_bwd: workspace too small");
     hipStream_t s = as_stream(stream);
     if (dx) {
-        size_t sm = ((size_t)K * C + (size_t)K * 64) * sizeof(float);
-        hipLaunchKernelGGL(xb ? k_seghead_dx<true> : k_seghead_dx<false>, dim3(cdiv(V, 64), N), dim3(256), sm, s, dlogits, w,
-                           dx, V, C, K, accumulate);
+        if (C % 4 == 0 && C / 4 <= 256 && V % 4 == 0 && (((uintptr_t)dx | (uintptr_t)w | (uintptr_t)dlogits) & 15) == 0) {
+            const long R = 256 / (C / 4);
+            long nb = cdiv(V / 4, R);
+            if (nb > 8192) nb = 8192;
+            hipLaunchKernelGGL(xb ? k_seghead_dx4<true> : k_seghead_dx4<false>, dim3((unsigned)nb, N), dim3(256), 0, s, dlogits, w,
+                               dx, V, C, K, accumulate);
+        } else {
+            size_t sm = ((size_t)K * C + (size_t)K * 64) * sizeof(float);
+            hipLaunchKernelGGL(xb ? k_seghead_dx<true> : k_seghead_dx<false>, dim3(cdiv(V, 64), N), dim3(256), sm, s, dlogits, w,
+                               dx, V, C, K, accumulate);
+        }
         if (check_launch("seghead_dx")) return 1;
     }
     if (dw) {
