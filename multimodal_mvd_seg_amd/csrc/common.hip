@@ -51,6 +51,13 @@ __global__ void k_nchw_to_ndhwc(const float *__restrict__ src, float *__restrict
         if (c < C && v < V) dst[((size_t)n * V + v) * C + c] = tile[tx][r];
     }
 }
+// C == 4 (the network input): a thread gathers its voxel from the four planes (coalesced per plane) and writes one float4
+__global__ void k_nchw_to_ndhwc_c4(const float *__restrict__ src, float *__restrict__ dst, long V) {
+    const int n = blockIdx.y;
+    const float *s = src + (size_t)n * 4 * V;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x)
+        *reinterpret_cast<float4 *>(dst + ((size_t)n * V + v) * 4) = make_float4(s[v], s[V + v], s[2 * V + v], s[3 * V + v]);
+}
 __global__ void k_ndhwc_to_nchw(const float *__restrict__ src, float *__restrict__ dst, int C, long V) {
     __shared__ float tile[32][33];
     long v0 = (long)blockIdx.x * 32;
@@ -123,6 +130,12 @@ int mvd_pack_weight(const float *w, float *wf, float *wb, int K, int C, int T, i
 
 int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *stream) {
     MVD_REQUIRE(src && dst && N > 0 && C > 0 && V > 0 && N <= 65535, "nchw_to_ndhwc: bad arguments");
+    if (C == 4 && (((uintptr_t)dst) & 15) == 0) {
+        long bx = cdiv(V, 256);
+        if (bx > 8192) bx = 8192;
+        hipLaunchKernelGGL(k_nchw_to_ndhwc_c4, dim3((unsigned)bx, N), dim3(256), 0, as_stream(stream), src, dst, V);
+        return check_launch("nchw_to_ndhwc");
+    }
     dim3 g(cdiv(V, 32), cdiv(C, 32), N);
     hipLaunchKernelGGL(k_nchw_to_ndhwc, g, dim3(256), 0, as_stream(stream), src, dst, C, V);
     return check_launch("nchw_to_ndhwc");
