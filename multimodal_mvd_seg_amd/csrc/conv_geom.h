@@ -79,6 +79,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
 int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u, const float *bias, float *y1, float *y2,
              hipStream_t s, float *stats = nullptr, int *stats_done = nullptr);
 int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s);
+int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const float *dy, const float *wb, float *dx,
+             hipStream_t s);
 int pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf, float *const *ub,
                        const int *K, const int *C, const int *T, const int *transposed, hipStream_t s);
 int wino_mode();                          // MVD_WINO: 0 off, 1 F(2,3) along W, 2 F(2x2,3x3) (default)

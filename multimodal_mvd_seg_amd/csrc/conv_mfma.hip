@@ -667,6 +667,146 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stride-2 input gradient
+// dx of a 3x3x3 stride-2 pad-1 conv: dx[i] = sum over (o, t) with 2 o + t - 1 = i of dy[o] W[t].  Per axis an even i = 2 j
+// meets only (t = 1, o = j); an odd i = 2 j + 1 meets (t = 0, o = j + 1) and (t = 2, o = j): eight parity classes with
+// 1 .. 8 taps.  The per-class launches of the gather engine re-stage the dy tile eight times (the 1- and 2-tap classes
+// for 16-32 MFMAs per stage); here ONE workgroup stages a 3 x 5 x 9 dy tile per 32-channel chunk (19 KB) and its eight
+// waves each take one class (two 32-voxel M tiles: 2 x 4 x 8 positions j).  The classes are unbalanced (1 .. 8 taps), but
+// the tile is small enough for several workgroups per CU, so other workgroups' waves fill the pipe.
+// Weights: the packed dgrad layout [kk][t][h][c][16] straight from L2, one tap ahead.
+struct Dg2Tile {
+    int ntd, nth, ntw, ncb, nitems, C;
+};
+__global__ __launch_bounds__(512, 2) void k_dgrad32s(const FwdGeom g, const Dg2Tile tg, const float *__restrict__ dy,
+                                                     const float *__restrict__ wb, float *__restrict__ dx) {
+    __shared__ __attribute__((aligned(16))) float Xs[135 * 36];
+    constexpr int XS = 36;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= tg.nitems) return;
+    unsigned r_ = (unsigned)item;
+    const int cb = (int)(r_ % (unsigned)tg.ncb); r_ /= (unsigned)tg.ncb;
+    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+    const int td_ = (int)(r_ % (unsigned)tg.ntd);
+    const int n = (int)(r_ / (unsigned)tg.ntd);
+    // here g.Di/Hi/Wi = dy grid (conv output), g.Dy/Hy/Wy = dx grid (conv input), g.C1 = K (reduce), tg.C = channels of dx
+    const int K = g.C1, C = tg.C;
+    const int nch = K >> 5;
+    const int oz0 = td_ * 2, oy0 = th_ * 4, ox0 = tw_ * 8;
+    // balance: wave w takes class w on M tile 0 (plane oz0) and the complementary class 7 - w on M tile 1 (plane oz0 + 1):
+    // 2^a + 2^(3-a) = 6 or 9 tap groups per wave instead of 1 .. 8
+    const int ccol = cb * 32 + i;
+    const float *wlane = wb + (((size_t)h * C + ccol) << 4);
+    const size_t wtap = (size_t)2 * C * 16;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+
+    for (int kk = 0; kk < nch; kk++) {
+        __syncthreads();
+        for (int idx = tid; idx < 135 * 8; idx += 512) {
+            const int slot = idx >> 3, part = idx & 7;
+            const int ez = slot / 45, rem = slot - ez * 45;
+            const int ey = rem / 9, ex = rem - ey * 9;
+            const int oz = oz0 + ez, oy = oy0 + ey, ox = ox0 + ex;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oz < g.Di && oy < g.Hi && ox < g.Wi)
+                v = *reinterpret_cast<const float4 *>(dy + ((((size_t)n * g.Di + oz) * g.Hi + oy) * g.Wi + ox) * K + kk * 32 +
+                                                      part * 4);
+            *reinterpret_cast<float4 *>(Xs + (size_t)slot * XS + part * 4) = v;
+        }
+        __syncthreads();
+        const float *wc = wlane + (size_t)kk * 27 * wtap;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int q = m ? 7 - wave : wave;
+            const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+            const float4 *xm = reinterpret_cast<const float4 *>(Xs + (size_t)((m * 5 + (i >> 3)) * 9 + (i & 7)) * XS + h * 16);
+            // the class's taps: per axis (t = 1, d = 0) for an even coordinate, (t = 0, d = 1) and (t = 2, d = 0) for an odd
+            // one; tap j of the 2^popcount(q) taps takes one bit of j per odd axis (z first).  Weights one tap ahead.
+            const int ntq = 1 << (pz + py + px);
+            auto tap_of = [&](int j, int &t, int &so) {
+                const int bz = pz ? (j >> (py + px)) & 1 : 0, by = py ? (j >> px) & 1 : 0, bx = px ? j & 1 : 0;
+                const int tz = pz ? (bz ? 2 : 0) : 1, ty = py ? (by ? 2 : 0) : 1, tx = px ? (bx ? 2 : 0) : 1;
+                const int dz = (pz && !bz) ? 1 : 0, dyy = (py && !by) ? 1 : 0, dxx = (px && !bx) ? 1 : 0;
+                t = (tz * 3 + ty) * 3 + tx;
+                so = (dz * 5 + dyy) * 9 + dxx;
+            };
+            float4 wv[2][4];
+            int t0, so0;
+            tap_of(0, t0, so0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) wv[0][e] = *reinterpret_cast<const float4 *>(wc + (size_t)t0 * wtap + e * 4);
+            for (int j = 0; j < ntq; j += 2) {  // two taps per trip: static buffer indices (ntq is 1, 2, 4 or 8)
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (j + u < ntq) {  // wave-uniform
+                        int t, so, tn, son;
+                        tap_of(j + u, t, so);
+                        tap_of(j + u + 1 < ntq ? j + u + 1 : j + u, tn, son);
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            wv[(u + 1) & 1][e] = *reinterpret_cast<const float4 *>(wc + (size_t)tn * wtap + e * 4);
+                        float4 af[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) af[e] = xm[so * (XS / 4) + e];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e].x, wv[u][e].x, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e].y, wv[u][e].y, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e].z, wv[u][e].z, acc[m], 0, 0, 0);
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e].w, wv[u][e].w, acc[m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // dx voxel of accumulator row r (lane half h) of M tile m: j = (oz0 + m, oy0 + (r >> 2), ox0 + (r & 3) + 4 h), i = 2 j + p
+    float *xl = dx + (size_t)(2 * 4 * h) * C + ccol;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int q = m ? 7 - wave : wave;
+        const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+        const int iz = 2 * (oz0 + m) + pz;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int iy = 2 * (oy0 + (r >> 2)) + py, ixu = 2 * (ox0 + (r & 3)) + px;  // wave-uniform
+            const size_t uo = ((((size_t)n * g.Dy + iz) * g.Hy + iy) * g.Wy + ixu) * C;
+            if (iz < g.Dy && iy < g.Hy && ixu + 8 * h < g.Wy) xl[uo] = acc[m][r];
+        }
+    }
+}
+
+int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const float *dy, const float *wb, float *dx,
+             hipStream_t s) {
+    if (C % 32 || K % 32 || (((uintptr_t)dy | (uintptr_t)wb) & 15)) return -1;
+    FwdGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N;
+    g.Di = Do; g.Hi = Ho; g.Wi = Wo;
+    g.Dy = D; g.Hy = H; g.Wy = W;
+    g.C1 = K;
+    Dg2Tile tg;
+    tg.ntd = (Do + 1) / 2; tg.nth = (Ho + 3) / 4; tg.ntw = (Wo + 7) / 8;
+    tg.ncb = C / 32;
+    tg.C = C;
+    const long nitems = (long)N * tg.ntd * tg.nth * tg.ntw * tg.ncb;
+    if (nitems > (1L << 30)) return -1;
+    tg.nitems = (int)nitems;
+    const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_dgrad32s, dim3(grid), dim3(512), 0, s, g, tg, dy, wb, dx);
+    return check_launch("conv dgrad (stride 2, fused parity classes)");
+}
+
 static int num_cus();
 static int launch_fwd32s(const FwdGeom &g, const float *a1, const float *a2, const float *w, const float *bias, float *y1,
                          float *y2, hipStream_t s) {

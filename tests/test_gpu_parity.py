@@ -944,3 +944,38 @@ def test_trainer_fed_by_device_loader_learns_and_postprocesses():
     from multimodal_mvd_seg_amd import ops
     _, count = ops.cc_label(ops.seg_label_mask(cleaned, [1, 2]), 26)
     assert int(count.item()) <= 2 and bool(((cleaned == hard) | (cleaned == 0)).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,K,sp,N", [
+    (32, 64, (8, 8, 16), 1),      # whole tiles
+    (32, 32, (9, 7, 13), 2),      # odd sizes: the last odd-parity voxel has no o = j + 1 neighbour, ragged tiles
+    (64, 96, (6, 10, 18), 1),     # two input-gradient channel blocks, three reduce chunks
+])
+def test_stride2_dgrad_fused_parity_classes_vs_fp64(C, K, sp, N):
+    """Input gradient of the 3x3x3 stride-2 conv through the fused eight-class kernel (forced on for small problems)
+    against fp64 and against the per-class gather launches."""
+    from multimodal_mvd_seg_amd import ops
+    from multimodal_mvd_seg_amd._lib import call
+    g = torch.Generator().manual_seed(C + K + sp[1])
+    x = torch.randn(N, C, *sp, generator=g)
+    w = torch.randn(K, C, 3, 3, 3, generator=g) * (1.0 / np.sqrt(27 * C))
+    b = torch.randn(K, generator=g) * 0.1
+    xr = x.double().requires_grad_()
+    ref = F.conv3d(xr, w.double(), b.double(), 2, 1)
+    gy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(gy)
+    outs = {}
+    try:
+        for mode, mi in (("fused", 1), ("classes", -1)):
+            call("mvd_set_wino_min_items", mi)
+            gx = G(x, True)
+            y = ops.Conv3dFn.apply(gx, None, G(w, True), G(b, True), (2, 2, 2))
+            y.backward(G(gy.float()))
+            outs[mode] = gx.grad
+            close(y, ref.detach(), 1e-5, 1e-5, "y")
+    finally:
+        call("mvd_set_wino_min_items", -1)
+    close(outs["fused"], xr.grad, 1e-5, 1e-5, "dx fused")
+    close(outs["classes"], xr.grad, 1e-5, 1e-5, "dx per class")
+    close(outs["fused"], outs["classes"].cpu(), 1e-5, 1e-5, "fused vs per class")
