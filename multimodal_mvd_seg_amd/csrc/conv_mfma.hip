@@ -1929,13 +1929,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallc(const WgradGeom g, cons
     const int row = wave * 32 + i;
     const bool rvalid = row < g.ntaps * C;
     const int rtap = rvalid ? row / C : 0, rc = rvalid ? row % C : 0;
-    const int arow = (toffs[rtap] * C + rc) * 4;  // byte offset added to slot*C*4
+    // byte offset added to slot*C*4; the lane half h is the second voxel of the pair (s2 even, TW a power of two >= 2: it
+    // only moves wx by one), so it is a per-lane constant here and the step's slot offsets stay wave-uniform
+    const int arow = (toffs[rtap] * C + rc) * 4 + h * g.sa[2] * C * 4;
     const int k0 = kb * 32;
     const int kvalid = (K - k0) < 32 ? (K - k0) : 32;
     const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
     const int TV = tg.TD * tg.TH * tg.TW;
     const int na = tg.nslotsA * PARTS, nb = tg.nslotsB * 8;
-    const int tb0 = tg.toffB[0] * 128 + i * 4;
+    const int tb0 = tg.toffB[0] * 128 + i * 4 + h * g.sb[2] * 128;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -1981,7 +1983,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallc(const WgradGeom g, cons
     };
     const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
     auto read_ops = [&](int s2, float &av, float &bv) {
-        const int v = (s2 < TV ? s2 : TV - 2) + h;
+        const int v = s2 < TV ? s2 : TV - 2;  // wave-uniform
         const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
         const int sa_ = ((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2];
         const int sb_ = ((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2];
