@@ -926,6 +926,7 @@ def test_trainer_fed_by_device_loader_learns_and_postprocesses():
         b = next(dl)
         assert b["data"].is_cuda and len(b["target"]) == len(tr._get_deep_supervision_scales())
         losses.append(float(tr.train_step(b)["loss"]))
+    print('feed-trained losses', np.mean(losses[:5]), np.mean(losses[-10:]))
     assert np.mean(losses[-10:]) < np.mean(losses[:5]) - 0.3, (losses[:5], losses[-10:])
     # predict one whole case tile by tile, argmax, keep the two largest components of the foreground
     tr.set_deep_supervision_enabled(False)
@@ -939,6 +940,7 @@ def test_trainer_fed_by_device_loader_learns_and_postprocesses():
     fg = (hard > 0)
     ref_fg = torch.from_numpy(seg[0] > 0).to(DEV)
     dice = 2.0 * float((fg & ref_fg).sum()) / max(1.0, float(fg.sum() + ref_fg.sum()))
+    print('feed-trained foreground dice', dice)
     assert dice > 0.6, dice
     cleaned = PP.remove_all_but_largest_component_from_segmentation(hard, [1, 2], 0)
     from multimodal_mvd_seg_amd import ops
