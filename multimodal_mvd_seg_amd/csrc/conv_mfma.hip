@@ -1839,28 +1839,37 @@ __global__ __launch_bounds__(768, 1) void k_wgrad_wino2w12(const WgradGeom g, co
 }
 
 // dw[k][c][gz][i][j] = sum_{a,b} G[a][i] G[b][j] (sum_split M[split][gz][a][b][c][k])   (fp64, fixed order)
-__global__ __launch_bounds__(256) void k_wgrad_reduce_wino2(const float *__restrict__ partial, float *__restrict__ dw,
-                                                            int C, int K, int nsplit) {
+// 1024 threads = 64 outputs x 4 position rows a x 4 split groups q (the small layers have only 3*C*K / 64 = 48..96
+// workgroups: a quarter of the splits per thread keeps enough loads in flight to stream the ~50 MB of partials)
+__global__ __launch_bounds__(1024) void k_wgrad_reduce_wino2(const float *__restrict__ partial, float *__restrict__ dw,
+                                                             int C, int K, int nsplit) {
+    __shared__ double redq[4][4][4][64];  // [q][a][b][e]
     __shared__ double red[4][3][64];
     const long CK = (long)C * K;
     const long per = 48 * CK;   // one split
     const long nout = 3 * CK;   // (gz, c, k)
-    const int e = threadIdx.x & 63, a = threadIdx.x >> 6;
+    const int e = threadIdx.x & 63, a = (threadIdx.x >> 6) & 3, q = threadIdx.x >> 8;
     const long j = (long)blockIdx.x * 64 + e;
     double m[4] = {0, 0, 0, 0};
     if (j < nout) {
         const long gz = j / CK, ck = j - gz * CK;
         const float *src = partial + ((size_t)(gz * 4 + a) * 4) * CK + ck;
-        for (int sp = 0; sp < nsplit; sp++) {
+        for (int sp = q; sp < nsplit; sp += 4) {
 #pragma unroll
             for (int bq = 0; bq < 4; bq++) m[bq] += (double)src[(size_t)sp * per + (size_t)bq * CK];
         }
     }
+#pragma unroll
+    for (int bq = 0; bq < 4; bq++) redq[q][a][bq][e] = m[bq];
+    __syncthreads();
+    if (q != 0) return;  // whole waves
+#pragma unroll
+    for (int bq = 0; bq < 4; bq++) m[bq] = ((redq[0][a][bq][e] + redq[1][a][bq][e]) + redq[2][a][bq][e]) + redq[3][a][bq][e];
     // row a of M times G: (M G)_aj
     red[a][0][e] = m[0] + 0.5 * (m[1] + m[2]);
     red[a][1][e] = 0.5 * (m[1] - m[2]);
     red[a][2][e] = 0.5 * (m[1] + m[2]) + m[3];
-    __syncthreads();
+    __syncthreads();  // the q != 0 waves have terminated: the hardware barrier only counts the four live ones
     if (a != 0 || j >= nout) return;
     const long gz = j / CK, ck = j - gz * CK;
     const int c = (int)(ck / K), k = (int)(ck - (long)c * K);
@@ -2424,7 +2433,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                     if (check_launch("conv wgrad dbias reduce")) return 1;
                     *dbias_done = 1;
                 }
-                hipLaunchKernelGGL(k_wgrad_reduce_wino2, dim3(cdiv((long)3 * C * g.K, 64)), dim3(256), 0, s, partial, dw, C,
+                hipLaunchKernelGGL(k_wgrad_reduce_wino2, dim3(cdiv((long)3 * C * g.K, 64)), dim3(1024), 0, s, partial, dw, C,
                                    g.K, tg.nsplit);
                 return check_launch("conv wgrad reduce (winograd 2-D)");
             }
