@@ -237,6 +237,13 @@ int mvd_kl_fwd_bf16(const uint16_t *ys, const uint16_t *yt, float *out, int N, i
 int mvd_kl_bwd_bf16(const uint16_t *ys, const uint16_t *yt, const float *gscale_dev, float gscale_host, uint16_t *gs,
                     uint16_t *gt, int N, int C, long V, float T, float eps_s, void *stream);
 
+/* Plain feature MSE: l2_loss(input, target, channel_wise=False) = mean(|a - b|^2) over all n elements
+ * (nnunetv2/training/loss/other_loss.py:77-78).  Elementwise: any dense layout, both tensors in the same one.
+ * out[0] = loss; bwd writes ga = g[0] * 2 (a - b) / n and gb = -ga (either may be NULL). */
+size_t mvd_mse_workspace_bytes(long n);
+int mvd_mse_fwd(const float *a, const float *b, float *out, long n, void *ws, size_t ws_bytes, void *stream);
+int mvd_mse_bwd(const float *a, const float *b, const float *g_dev, float *ga, float *gb, long n, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Soft skeleton primitives (K9).  Replace soft_erode / soft_dilate of soft_skeleton.py:6-22 on planar volumes
  * [NC, D, H, W].  Bit-exact vs torch CPU (min/max only).  bwd reproduces autograd's routing: max_pool3d sends the

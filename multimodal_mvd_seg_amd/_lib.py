@@ -91,6 +91,9 @@ SIGNATURES = {
                            c_int, _P]),
     "mvd_kl_fwd_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_long, c_float, c_float, _P, c_size_t, _P]),
     "mvd_kl_bwd_bf16": (c_int, [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_long, c_float, c_float, _P]),
+    "mvd_mse_workspace_bytes": (c_size_t, [c_long]),
+    "mvd_mse_fwd": (c_int, [_P, _P, _P, c_long, _P, c_size_t, _P]),
+    "mvd_mse_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, _P]),
     "mvd_soft_erode_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_soft_erode_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_soft_dilate_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -708,6 +708,41 @@ static inline bool kl_rows_ok(int C, long V, long sn, long sc, long sv, int pad)
     return !pad && (C == 4 || C == 8 || C == 16 || C == 32) && sc == 1 && sv == C && sn == V * (long)C;
 }
 
+// ---- plain MSE: l2_loss(channel_wise=False) = mean(|a-b|^2) (other_loss.py:77-78); elementwise, layout-agnostic
+__global__ void k_mse_fwd(const float *__restrict__ a, const float *__restrict__ b, double *__restrict__ partial, long n) {
+    __shared__ double red[16];
+    double acc[1] = {0.0};
+    const long n4 = n >> 2;
+    const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 x = a4[i], y = b4[i];
+        const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+        acc[0] += (double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2 + (double)d3 * d3;
+    }
+    if (blockIdx.x == 0 && (long)threadIdx.x < (n & 3)) {
+        const float d = a[n4 * 4 + threadIdx.x] - b[n4 * 4 + threadIdx.x];
+        acc[0] += (double)d * d;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+// out[0] = (sum_b partial[b]) / n, summed in a fixed order by one wave
+__global__ void k_mse_finish(const double *__restrict__ partial, float *__restrict__ out, int nblk, long n) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = (float)(s / (double)n);
+}
+__global__ void k_mse_bwd(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ g,
+                          float *__restrict__ ga, float *__restrict__ gb, long n) {
+    const float c = g[0] * (float)(2.0 / (double)n);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = c * (a[i] - b[i]);
+        if (ga) ga[i] = v;
+        if (gb) gb[i] = -v;
+    }
+}
+
 }  // namespace mvd
 
 using namespace mvd;
@@ -893,6 +928,25 @@ int mvd_label_mask(const float *labels, float *mask, long n, float value, void *
     MVD_REQUIRE(labels && mask && n > 0, "label_mask: bad arguments");
     hipLaunchKernelGGL(k_label_mask, dim3(grid_for(n, 4096)), dim3(256), 0, as_stream(stream), labels, mask, n, value);
     return check_launch("label_mask");
+}
+
+size_t mvd_mse_workspace_bytes(long n) { return (size_t)grid_for(n, 4096) * sizeof(double) + 256; }
+int mvd_mse_fwd(const float *a, const float *b, float *out, long n, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(a && b && out && ws && n > 0, "mse_fwd: bad arguments");
+    MVD_REQUIRE(((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0, "mse_fwd: inputs must be 16-byte aligned");
+    MVD_REQUIRE(ws_bytes >= mvd_mse_workspace_bytes(n), "mse_fwd: workspace too small");
+    const long bx = grid_for(n, 4096);
+    double *partial = reinterpret_cast<double *>(ws);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_mse_fwd, dim3(bx), dim3(256), 0, s, a, b, partial, n);
+    if (check_launch("mse_fwd")) return 1;
+    hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(64), 0, s, partial, out, (int)bx, n);
+    return check_launch("mse_finish");
+}
+int mvd_mse_bwd(const float *a, const float *b, const float *g_dev, float *ga, float *gb, long n, void *stream) {
+    MVD_REQUIRE(a && b && g_dev && (ga || gb) && n > 0, "mse_bwd: bad arguments");
+    hipLaunchKernelGGL(k_mse_bwd, dim3(grid_for(n, 2048)), dim3(256), 0, as_stream(stream), a, b, g_dev, ga, gb, n);
+    return check_launch("mse_bwd");
 }
 
 size_t mvd_kl_workspace_bytes(int N, long V) { return (size_t)grid_for((long)N * V, 2048) * sizeof(double) + 256; }

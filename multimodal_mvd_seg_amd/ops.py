@@ -719,6 +719,42 @@ class DistillKLFn(Function):
         return gs, gt, None, None, None
 
 
+class MseFn(Function):
+    """l2_loss(channel_wise=False) = mean(|a - b|^2) (other_loss.py:77-78)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_cuda(a, b)
+        if a.shape != b.shape:
+            raise RuntimeError("l2_loss: shape mismatch")
+        if a.dtype != torch.float32 or b.dtype != torch.float32:
+            raise RuntimeError("l2_loss: fp32 inputs (widen bf16 feature maps first)")
+        # elementwise: both operands only have to share ONE dense layout (planar or NDHWC)
+        if not (a.is_contiguous() or _is_cl3d(a)):
+            a = a.contiguous()
+        if a.stride() != b.stride():
+            b = b.contiguous(memory_format=CL3D) if (_is_cl3d(a) and not a.is_contiguous()) else b.contiguous()
+            if a.stride() != b.stride():
+                a = a.contiguous()
+                b = b.contiguous()
+        n = a.numel()
+        out = torch.empty((1,), dtype=torch.float32, device=a.device)
+        ws = _Workspace.get(query("mvd_mse_workspace_bytes", n), a.device)
+        call("mvd_mse_fwd", _p(a), _p(b), _p(out), n, _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(a, b)
+        return out.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        call("mvd_mse_bwd", _p(a), _p(b), _p(g), _p(ga), _p(gb), a.numel(), _stream())
+        return ga, gb
+
+
 class SoftmaxSelectFn(Function):
     """softmax(logits, 1)[:, sel:sel+1] on planar logits."""
 

@@ -559,34 +559,9 @@ def test_cfg2_network_4x64cube_train_step_vs_oracle():
         close(p, ref_params[n].detach(), 1e-5, 0, "param after step: " + n)
 
 
-def test_cfg2_network_gradients_vs_fp64_truth():
-    """Gradient parity measured against the SAME network evaluated in fp64: the backward pass through 22 InstanceNorm
-    layers is ill-conditioned in fp32 (torch-CPU fp32 itself is ~1e-3 relative off the fp64 truth), so the bar is
-    'no worse than 4x the fp32 oracle's own error (+1e-5)', per parameter tensor, in relative L2."""
-    import copy
-    # 4 stages at 32^3: 4^3 voxels at the bottleneck.  (With 2^3-voxel InstanceNorms the fp32 backward is chaotic:
-    # tools/diag_grad.py shows 3e-4 .. 1e-2 relative deviations from the fp64 truth for torch-CPU, the scalar engine
-    # and the MFMA engine alike, while every single op is accurate to <1e-6 -- tools/diag_ops.py.)
-    ora, loss_fn, batch, tr = _cfg2_pair(32, batch_size=2, n_stages=4)
-    loss_fn(ora(batch["data"]), batch["target"]).backward()
-    ora64 = copy.deepcopy(ora).double()
-    for p in ora64.parameters():
-        p.grad = None
-    loss_fn(ora64(batch["data"].double()), [t.double() for t in batch["target"]]).backward()
-    tr.optimizer.zero_grad()
-    tr.loss(tr.network(batch["data"].to(DEV)), [t.to(DEV) for t in batch["target"]]).backward()
-    g32 = dict(ora.named_parameters())
-    g64 = dict(ora64.named_parameters())
-    for n, p in tr.network.named_parameters():
-        r = g64[n].grad
-        nr = float(r.norm())
-        if nr < 1e-12:  # conv bias in front of InstanceNorm (analytically zero) / the zero-weighted lowest head
-            assert float(p.grad.abs().max()) < 1e-5, n
-            continue
-        e_hip = float((p.grad.cpu().double() - r).norm()) / nr
-        e_cpu = float((g32[n].grad.double() - r).norm()) / nr
-        # both errors are round-off of two fp32 evaluation orders (random variables of the same scale)
-        assert e_hip <= 5 * e_cpu + 5e-4, f"{n}: relL2 hip {e_hip:.2e} vs torch-fp32 {e_cpu:.2e}"
+# The gradient parity of the cfg-2 network (all six stages, against an fp64 evaluation with the LeakyReLU branch pattern of
+# the HIP forward), the per-block backward checks at the real cfg-2 layer shapes and the full 4x128^3 step live in
+# tests/test_gpu_cfg2.py.
 
 
 # ================================================================================================ inference (8f-1)

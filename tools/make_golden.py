@@ -7,6 +7,7 @@ restatement (the reference's own module is not importable -- SURVEY.md 8c).
 
 usage: python tools/make_golden.py
 """
+import ast
 import importlib.util
 import json
 import os
@@ -166,32 +167,151 @@ def reference_fixtures():
     print("wrote polylr.json he_init_stats.json topology_props.json")
 
 
-# ------------------------------------------------------------------ oracle-generated (reference not importable)
-def loss_fixtures():
+# ------------------------------------------------------------------ reference functions whose MODULE cannot be imported
+def ref_function(rel, func_name, class_name=None, **ns):
+    """Compiles ONE function definition out of a reference source file and returns it as a live function.  Used for
+    pure torch/numpy functions whose module fails at import time on an absent third-party package (other_loss.py ->
+    lightly, base_data_loader.py / nnUNetTrainer.py -> batchgenerators, sliding_window_prediction.py -> acvl_utils):
+    the function body itself is executed unchanged, so the fixtures below are reference-pinned.  Runs in the build
+    container only (needs /root/reference); nothing of the source text is stored."""
+    import typing
+    path = os.path.join(R, rel)
+    tree = ast.parse(open(path).read(), path)
+    body = tree.body
+    if class_name is not None:
+        body = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == class_name).body
+    node = next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == func_name)
+    node.decorator_list = []
+    code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+    glob = {"np": np, "torch": torch, "F": F, "Union": typing.Union, "Tuple": typing.Tuple, "List": typing.List}
+    glob.update(ns)
+    exec(code, glob)
+    return glob[func_name], f"{rel}:{node.lineno}-{node.end_lineno}"
+
+
+def extracted_reference_fixtures():
+    import types
+    # ---- distill_kl / l2_loss (other_loss.py:51-78); distill_kl carries a stray `self` first parameter
+    kl, kl_src = ref_function("training/loss/other_loss.py", "distill_kl")
+    l2, l2_src = ref_function("training/loss/other_loss.py", "l2_loss")
     for name, shape, T in (("distill_kl_c5_T1", (2, 5, 6, 6, 6), 1), ("distill_kl_c5_T4", (2, 5, 6, 6, 6), 4),
                            ("distill_kl_c1_T1", (2, 1, 6, 6, 6), 1), ("distill_kl_c1_T4", (2, 1, 6, 6, 6), 4)):
         g = gen(50)
         ys = (torch.randn(shape, generator=g) * 2).requires_grad_()
         yt = (torch.randn(shape, generator=g) * 2).requires_grad_()
-        l = LO.distill_kl(ys, yt, T)
+        l = kl(None, ys, yt, T)
         l.backward()
-        save(name + ".npz", source="oracle restatement of other_loss.py:51-64", T=T, ys=ys, yt=yt, loss=l,
-             gys=ys.grad, gyt=yt.grad)
+        assert torch.equal(l.detach(), LO.distill_kl(ys.detach(), yt.detach(), T)), "oracle distill_kl != reference"
+        save(name + ".npz", source="reference " + kl_src, T=T, ys=ys, yt=yt, loss=l, gys=ys.grad, gyt=yt.grad)
     for name, T in (("feat_kl_T1", 1), ("feat_kl_T4", 4)):
         g = gen(51)
         a = torch.randn(2, 32, 5, 6, 4, generator=g, requires_grad=True)
         b = torch.randn(2, 32, 5, 6, 4, generator=g, requires_grad=True)
-        l = LO.l2_loss(a, b, True, T)
+        l = l2(a, b, True, T)
         l.backward()
-        save(name + ".npz", source="oracle restatement of other_loss.py:67-76", T=T, a=a, b=b, loss=l, ga=a.grad,
-             gb=b.grad)
+        assert torch.equal(l.detach(), LO.l2_loss(a.detach(), b.detach(), True, T)), "oracle l2_loss != reference"
+        save(name + ".npz", source="reference " + l2_src, T=T, a=a, b=b, loss=l, ga=a.grad, gb=b.grad)
     g = gen(52)
     a = torch.randn(2, 8, 5, 6, 4, generator=g, requires_grad=True)
-    b = torch.randn(2, 8, 5, 6, 4, generator=g)
-    l = LO.l2_loss(a, b, False)
+    b = torch.randn(2, 8, 5, 6, 4, generator=g, requires_grad=True)
+    l = l2(a, b, False)
     l.backward()
-    save("l2_loss_plain.npz", source="oracle restatement of other_loss.py:78", a=a, b=b, loss=l, ga=a.grad)
+    assert torch.equal(l.detach(), LO.l2_loss(a.detach(), b.detach(), False))
+    save("l2_loss_plain.npz", source="reference " + l2_src, a=a, b=b, loss=l, ga=a.grad, gb=b.grad)
 
+    # ---- per-rank batch split (nnUNetTrainer.py:304-349): the method on a stub trainer, torch.distributed stubbed
+    cases = {}
+    for gb in range(2, 17):
+        for ws in range(1, 9):
+            if gb < ws:
+                continue
+            bs, ov = [], []
+            for rank in range(ws):
+                dist_stub = types.SimpleNamespace(get_world_size=lambda ws=ws: ws, get_rank=lambda rank=rank: rank)
+                fn, split_src = ref_function("training/nnUNetTrainer/nnUNetTrainer.py", "_set_batch_size_and_oversample",
+                                             "nnUNetTrainer", dist=dist_stub, print=lambda *a, **k: None)
+                me = types.SimpleNamespace(is_ddp=True, oversample_foreground_percent=0.33,
+                                           configuration_manager=types.SimpleNamespace(batch_size=gb))
+                fn(me)
+                bs.append(int(me.batch_size))
+                ov.append(float(me.oversample_foreground_percent))
+            o_bs, o_ov = SO.ddp_batch_split(gb, ws)
+            assert o_bs == bs and o_ov == ov, (gb, ws, bs, o_bs, ov, o_ov)
+            cases[f"{gb}_{ws}"] = {"batch_sizes": bs, "oversample": ov}
+    json.dump({"source": "reference " + split_src + " (method executed on a stub trainer per rank)", "cases": cases},
+              open(os.path.join(OUT, "ddp_split.json"), "w"))
+
+    # ---- sliding-window step placement and Gaussian importance map (sliding_window_prediction.py:10-56)
+    steps, steps_src = ref_function("inference/sliding_window_prediction.py", "compute_steps_for_sliding_window")
+    from scipy.ndimage import gaussian_filter
+    gauss, gauss_src = ref_function("inference/sliding_window_prediction.py", "compute_gaussian",
+                                    gaussian_filter=gaussian_filter)
+    sw = []
+    for image, tile, step in (((110,), (64,), 0.5), ((128, 128, 128), (128, 128, 128), 0.5),
+                              ((192, 256, 256), (128, 128, 128), 0.5), ((133, 160, 201), (64, 96, 128), 0.5),
+                              ((70, 70, 70), (64, 64, 64), 1.0), ((100, 300, 77), (48, 160, 64), 0.25),
+                              ((65, 64, 200), (64, 64, 64), 0.75)):
+        sw.append({"image_size": list(image), "tile_size": list(tile), "tile_step_size": step,
+                   "steps": [[int(v) for v in ax] for ax in steps(image, tile, step)]})
+    gm = []
+    for tile in ((8, 8, 8), (6, 10, 12), (16, 16, 16)):
+        m = gauss(tile, 1. / 8, 1000, torch.float32, torch.device("cpu"))
+        gm.append({"tile_size": list(tile), "sigma_scale": 0.125, "value_scaling_factor": 1000,
+                   "map": [float(v) for v in m.reshape(-1)]})
+    json.dump({"source": "reference " + steps_src + " and " + gauss_src, "steps": sw, "gaussian": gm},
+              open(os.path.join(OUT, "sw_steps.json"), "w"))
+
+    # ---- patch sampler (base_data_loader.py:64-139): get_bbox on a stub loader, numpy global RNG seeded per case
+    bbox, bbox_src = ref_function("training/dataloading/base_data_loader.py", "get_bbox", "nnUNetDataLoaderBase",
+                                  print=lambda *a, **k: None)
+    rng = np.random.default_rng(11)
+    out = []
+
+    def locs(shape, n):
+        if n == 0:
+            return np.zeros((0, 4), dtype=np.int64)
+        return np.stack([np.zeros(n, dtype=np.int64)] + [rng.integers(0, s, n) for s in shape], 1)
+
+    scen = []
+    for shape, patch, pad_extra in (((40, 50, 60), (32, 32, 32), (0, 0, 0)), ((20, 70, 33), (32, 48, 32), (0, 0, 0)),
+                                    ((30, 30, 30), (32, 32, 32), (0, 0, 0)), ((64, 64, 64), (32, 40, 48), (5, 4, 3)),
+                                    ((17, 90, 41), (16, 64, 48), (0, 7, 0))):
+        for force_fg in (False, True):
+            for variant in ("plain", "empty_class", "all_empty", "overwrite", "region_key", "ignore"):
+                scen.append((shape, patch, pad_extra, force_fg, variant))
+    for ci, (shape, patch, pad_extra, force_fg, variant) in enumerate(scen):
+        all_labels = (1, 2, 3)
+        cl = {1: locs(shape, 40), 2: locs(shape, 25), 3: locs(shape, 7)}
+        overwrite, has_ignore = None, False
+        if variant == "empty_class":
+            cl[2] = locs(shape, 0)
+        elif variant == "all_empty":
+            cl = {k: locs(shape, 0) for k in cl}
+        elif variant == "overwrite":
+            overwrite = 3
+        elif variant == "region_key":
+            cl[all_labels] = locs(shape, 30)  # the annotated-classes tuple key (removed when other classes exist)
+        elif variant == "ignore":
+            has_ignore = True
+            cl[all_labels] = locs(shape, 30 if ci % 2 else 0)
+        me = types.SimpleNamespace(need_to_pad=np.array(pad_extra, dtype=int), patch_size=patch,
+                                   has_ignore=has_ignore, annotated_classes_key=all_labels)
+        seed = 1000 + ci
+        np.random.seed(seed)
+        lbs, ubs = bbox(me, np.array(shape), force_fg, cl, overwrite)
+        tail = float(np.random.uniform())  # the RNG state after the call: pins the NUMBER and ORDER of draws
+        out.append({"shape": list(shape), "patch_size": list(patch), "need_to_pad": list(pad_extra),
+                    "force_fg": force_fg, "has_ignore": has_ignore, "overwrite_class": overwrite, "seed": seed,
+                    "annotated_classes_key": list(all_labels),
+                    "class_locations": [[(list(k) if isinstance(k, tuple) else k), v.tolist()] for k, v in cl.items()],
+                    "bbox_lbs": [int(v) for v in lbs], "bbox_ubs": [int(v) for v in ubs], "rng_tail": tail})
+    json.dump({"source": "reference " + bbox_src + " (method executed on a stub loader)", "cases": out},
+              open(os.path.join(OUT, "get_bbox.json"), "w"))
+    print("wrote distill_kl_* feat_kl_* l2_loss_plain ddp_split.json sw_steps.json get_bbox.json (reference-extracted)")
+
+
+# ------------------------------------------------------------------ oracle-generated (reference not importable)
+def loss_fixtures():
     # DC+CE on one level, batch_dice False/True
     for bd in (False, True):
         g = gen(53)
@@ -289,18 +409,6 @@ def mvd_step_fixture():
     save("mvd_tiny_step.npz", **out)
 
 
-def ddp_fixture():
-    res = {}
-    for gb in range(2, 17):
-        for ws in range(1, 9):
-            if gb >= ws:
-                bs, ov = SO.ddp_batch_split(gb, ws)
-                res[f"{gb}_{ws}"] = {"batch_sizes": bs, "oversample": ov}
-    json.dump({"source": "oracle restatement of nnUNetTrainer.py:304-349", "cases": res},
-              open(os.path.join(OUT, "ddp_split.json"), "w"))
-    print("wrote ddp_split.json")
-
-
 def persistence_fixtures():
     m = build_ref.load()
     assert m is not None, "run `python oracle/build_ref.py` first"
@@ -377,11 +485,14 @@ def persistence_fixtures():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "extracted":  # only the fixtures compiled out of reference function bodies
+        extracted_reference_fixtures()
+        sys.exit(0)
     conv_fixtures()
     instnorm_fixtures()
     reference_fixtures()
+    extracted_reference_fixtures()
     loss_fixtures()
     unet_step_fixture()
     mvd_step_fixture()
-    ddp_fixture()
     persistence_fixtures()
