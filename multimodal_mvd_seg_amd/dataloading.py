@@ -127,50 +127,63 @@ class DeviceDataLoader3D:
     def _probabilistic_oversampling(self, sample_idx):
         return np.random.uniform() < self.oversample_foreground_percent
 
+    def _corner_range(self, data_shape):
+        """(lowest, highest) admissible lower patch corner per axis.  A case smaller than the patch is padded on both
+        sides (the odd voxel goes to the upper side); `need_to_pad` widens the range by the margin the reference keeps
+        for its spatial transform."""
+        shape = np.asarray(data_shape, dtype=np.int64)
+        patch = np.asarray(self.patch_size, dtype=np.int64)
+        margin = np.maximum(np.asarray(self.need_to_pad, dtype=np.int64), patch - shape)
+        lowest = (-margin) // 2
+        highest = shape + margin // 2 + margin % 2 - patch
+        return lowest.tolist(), highest.tolist()
+
+    def _centre_class(self, force_fg, class_locations, overwrite_class, verbose):
+        """Which class (or region key) the patch must be centred on; None -> uniform corner.  One np.random.choice
+        when a foreground class has to be drawn, none otherwise."""
+        everything = self.annotated_classes_key
+        if not force_fg:
+            if not self.has_ignore:
+                return None
+            # ignore label present: stay inside the annotated area whenever the case has one
+            if len(class_locations[everything]) == 0:
+                print('Warning! No annotated pixels in image!')
+                return None
+            return everything
+        if class_locations is None:
+            raise AssertionError('if force_fg is set class_locations cannot be None')
+        if overwrite_class is not None and overwrite_class not in class_locations.keys():
+            raise AssertionError('desired class ("overwrite_class") does not have class_locations (missing key)')
+        present = [k for k in class_locations.keys() if len(class_locations[k]) > 0]
+        if len(present) > 1:
+            # the all-annotated-classes key only serves cases that have nothing more specific
+            for j, k in enumerate(present):
+                if isinstance(k, tuple) and k == everything:
+                    del present[j]
+                    break
+        if not present:
+            if verbose:
+                print('case does not contain any foreground classes')
+            return None
+        if overwrite_class is not None and overwrite_class in present:
+            return overwrite_class
+        return present[np.random.choice(len(present))]
+
     def get_bbox(self, data_shape, force_fg, class_locations, overwrite_class=None, verbose=False):
-        """base_data_loader.py:56-139"""
-        need_to_pad = self.need_to_pad.copy()
-        dim = len(data_shape)
-        for d in range(dim):
-            if need_to_pad[d] + data_shape[d] < self.patch_size[d]:
-                need_to_pad[d] = self.patch_size[d] - data_shape[d]
-        lbs = [- need_to_pad[i] // 2 for i in range(dim)]
-        ubs = [data_shape[i] + need_to_pad[i] // 2 + need_to_pad[i] % 2 - self.patch_size[i] for i in range(dim)]
-        if not force_fg and not self.has_ignore:
-            bbox_lbs = [np.random.randint(lbs[i], ubs[i] + 1) for i in range(dim)]
+        """Lower / upper corner of the patch to cut from a case of spatial shape `data_shape` -- the sampler of
+        nnUNetDataLoaderBase.get_bbox (base_data_loader.py:64-139) with the same arguments, result and numpy-RNG draw
+        order (tests/golden/get_bbox.json holds boxes AND the RNG state after each call, generated by the reference
+        method): centred on a random voxel of a random foreground class when `force_fg`, uniform otherwise."""
+        lowest, highest = self._corner_range(data_shape)
+        axes = range(len(data_shape))
+        cls = self._centre_class(force_fg, class_locations, overwrite_class, verbose)
+        voxels = class_locations[cls] if cls is not None else None
+        if voxels is not None and len(voxels) > 0:
+            centre = voxels[np.random.choice(len(voxels))]   # row = (channel, z, y, x)
+            corner = [max(lowest[i], int(centre[i + 1]) - self.patch_size[i] // 2) for i in axes]
         else:
-            if not force_fg and self.has_ignore:
-                selected_class = self.annotated_classes_key
-                if len(class_locations[selected_class]) == 0:
-                    print('Warning! No annotated pixels in image!')
-                    selected_class = None
-            elif force_fg:
-                assert class_locations is not None, 'if force_fg is set class_locations cannot be None'
-                if overwrite_class is not None:
-                    assert overwrite_class in class_locations.keys(), \
-                        'desired class ("overwrite_class") does not have class_locations (missing key)'
-                eligible = [i for i in class_locations.keys() if len(class_locations[i]) > 0]
-                tmp = [i == self.annotated_classes_key if isinstance(i, tuple) else False for i in eligible]
-                if any(tmp) and len(eligible) > 1:
-                    eligible.pop(np.where(tmp)[0][0])
-                if len(eligible) == 0:
-                    selected_class = None
-                    if verbose:
-                        print('case does not contain any foreground classes')
-                else:
-                    selected_class = eligible[np.random.choice(len(eligible))] if \
-                        (overwrite_class is None or (overwrite_class not in eligible)) else overwrite_class
-            else:
-                raise RuntimeError('lol what!?')
-            voxels = class_locations[selected_class] if selected_class is not None else None
-            if voxels is not None and len(voxels) > 0:
-                selected_voxel = voxels[np.random.choice(len(voxels))]
-                # first column of a location row is the channel index
-                bbox_lbs = [max(lbs[i], selected_voxel[i + 1] - self.patch_size[i] // 2) for i in range(dim)]
-            else:
-                bbox_lbs = [np.random.randint(lbs[i], ubs[i] + 1) for i in range(dim)]
-        bbox_ubs = [bbox_lbs[i] + self.patch_size[i] for i in range(dim)]
-        return bbox_lbs, bbox_ubs
+            corner = [int(np.random.randint(lowest[i], highest[i] + 1)) for i in axes]
+        return corner, [corner[i] + self.patch_size[i] for i in axes]
 
     def draw_mirror(self):
         """MirrorTransform's per-sample draw (batchgenerators, absent from the reference tree -- restated from its

@@ -19,17 +19,21 @@ from ._lib import call
 
 def compute_steps_for_sliding_window(image_size: Sequence[int], tile_size: Sequence[int], tile_step_size: float) \
         -> List[List[int]]:
-    """sliding_window_prediction.py:32-56."""
-    assert all(i >= j for i, j in zip(image_size, tile_size)), "image size must be as large or larger than patch_size"
-    assert 0 < tile_step_size <= 1, 'step_size must be larger than 0 and smaller or equal to 1'
-    target_step_sizes_in_voxels = [i * tile_step_size for i in tile_size]
-    num_steps = [int(np.ceil((i - k) / j)) + 1 for i, j, k in zip(image_size, target_step_sizes_in_voxels, tile_size)]
-    steps = []
-    for dim in range(len(tile_size)):
-        max_step_value = image_size[dim] - tile_size[dim]
-        actual_step_size = max_step_value / (num_steps[dim] - 1) if num_steps[dim] > 1 else 99999999999
-        steps.append([int(np.round(actual_step_size * i)) for i in range(num_steps[dim])])
-    return steps
+    """Tile origins per axis (same name / arguments / result as sliding_window_prediction.py:32-56; pinned to the
+    reference function by tests/golden/sw_steps.json): the fewest tiles whose spacing does not exceed
+    tile_step_size * tile, spread evenly from 0 to image - tile."""
+    image, tile = np.asarray(image_size, dtype=np.int64), np.asarray(tile_size, dtype=np.int64)
+    if image.shape != tile.shape or np.any(image < tile):
+        raise ValueError("image size must be as large or larger than patch_size")
+    if not 0 < tile_step_size <= 1:
+        raise ValueError("step_size must be larger than 0 and smaller or equal to 1")
+    span = image - tile                                      # last admissible origin
+    count = np.ceil(span / (tile * tile_step_size)).astype(np.int64) + 1
+    origins = []
+    for last, n in zip(span.tolist(), count.tolist()):
+        pitch = last / (n - 1) if n > 1 else 0.0
+        origins.append([int(np.round(pitch * i)) for i in range(n)])
+    return origins
 
 
 def _gaussian_kernel1d(sigma: float, radius: int) -> np.ndarray:

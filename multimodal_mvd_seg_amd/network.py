@@ -62,6 +62,18 @@ class ConvDropoutNormReLU(nn.Module):
             raise NotImplementedError("dropout is not on the reference's path (get_network_from_plans.py:43)")
         if nonlin_first:
             raise NotImplementedError("nonlin_first=False on the reference's path")
+        # the fused kernel IS InstanceNorm3d(affine) + LeakyReLU (get_network_from_plans.py:41-44): anything else in the
+        # plans would silently compute something different, so refuse it
+        if norm_op is not None and not (isinstance(norm_op, type) and issubclass(norm_op, nn.InstanceNorm3d)):
+            raise NotImplementedError(f"norm_op {norm_op!r}: only nn.InstanceNorm3d is on the reference's path")
+        if norm_op is None:
+            raise NotImplementedError("norm_op=None: the fused conv block always normalises (InstanceNorm3d)")
+        if nonlin is not None and not (isinstance(nonlin, type) and issubclass(nonlin, nn.LeakyReLU)):
+            raise NotImplementedError(f"nonlin {nonlin!r}: only nn.LeakyReLU is on the reference's path")
+        if nonlin is None:
+            raise NotImplementedError("nonlin=None: the fused conv block always applies LeakyReLU")
+        if not dict(norm_op_kwargs or {'affine': True}).get('affine', False):
+            raise NotImplementedError("InstanceNorm3d(affine=False) is not on the reference's path")
         self.input_channels, self.output_channels = input_channels, output_channels
         self.stride = _tup3(stride)
         k = _tup3(kernel_size)
@@ -70,14 +82,14 @@ class ConvDropoutNormReLU(nn.Module):
         norm_op_kwargs = norm_op_kwargs or {'eps': 1e-5, 'affine': True}
         self.norm = HipInstanceNorm3d(output_channels, **norm_op_kwargs)
         nonlin_kwargs = dict(nonlin_kwargs or {'inplace': True})
-        self.nonlin = (nonlin or nn.LeakyReLU)(**nonlin_kwargs)
+        self.nonlin = nonlin(**nonlin_kwargs)
         self.all_modules = nn.Sequential(self.conv, self.norm, self.nonlin)
         self.precision = "fp32"  # "bf16": see set_precision()
 
     def forward(self, x, x2=None):
         y = self.conv(x, x2)
-        slope = getattr(self.nonlin, 'negative_slope', 0.01)
-        return ops.InstanceNormLeakyReLUFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, slope,
+        return ops.InstanceNormLeakyReLUFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps,
+                                                 self.nonlin.negative_slope,
                                                  self.precision == "bf16")
 
     def compute_conv_feature_map_size(self, input_size):
@@ -198,35 +210,38 @@ class UNetDecoder(nn.Module):
         self.seg_layers = nn.ModuleList(seg_layers)
 
     def forward(self, skips, return_last_feature=False):
-        lres_input = skips[-1]
-        seg_outputs = []
-        for s in range(len(self.stages)):
-            x = self.transpconvs[s](lres_input)
-            # torch.cat((x, skip), 1) is never materialised: the first conv reads both pointers (UNetDecoder.py:107)
-            x = self.stages[s](x, skips[-(s + 2)])
+        """Bottom-up: up-sample, fuse with the encoder feature of that resolution, refine, emit logits.  Same contract
+        as UNetDecoder.py:104-121: list of logits, highest resolution first, with deep supervision; one tensor without."""
+        feat = skips[-1]
+        last = len(self.stages) - 1
+        logits = []
+        for level, (up, refine, head) in enumerate(zip(self.transpconvs, self.stages, self.seg_layers)):
+            # the concatenation of (up-sampled, skip) is never materialised: the first conv reads both pointers
+            feat = refine(up(feat), skips[-(level + 2)])
             if self.deep_supervision:
-                seg_outputs.append(self.seg_layers[s](x))
-            elif s == (len(self.stages) - 1):
-                seg_outputs.append(self.seg_layers[-1](x))
-            lres_input = x
-        seg_outputs = seg_outputs[::-1]
-        r = seg_outputs if self.deep_supervision else seg_outputs[0]
-        if return_last_feature:
-            return r, lres_input
-        return r
+                logits.append(head(feat))
+            elif level == last:
+                logits.append(self.seg_layers[-1](feat))
+        out = logits[::-1] if self.deep_supervision else logits[0]
+        return (out, feat) if return_last_feature else out
 
     def compute_conv_feature_map_size(self, input_size):
-        skip_sizes = []
-        for s in range(len(self.encoder.strides) - 1):
-            skip_sizes.append([i // j for i, j in zip(input_size, self.encoder.strides[s])])
-            input_size = skip_sizes[-1]
-        output = np.int64(0)
-        for s in range(len(self.stages)):
-            output += self.stages[s].compute_conv_feature_map_size(skip_sizes[-(s + 1)])
-            output += np.prod([self.encoder.output_channels[-(s + 2)], *skip_sizes[-(s + 1)]], dtype=np.int64)
-            if self.deep_supervision or (s == (len(self.stages) - 1)):
-                output += np.prod([self.num_classes, *skip_sizes[-(s + 1)]], dtype=np.int64)
-        return output
+        """Number of feature-map elements the decoder produces for one sample (the planner's VRAM proxy,
+        UNetDecoder.py:123-150): per resolution the refined maps, the up-sampled map and the logits that are emitted."""
+        sizes, cur = [], list(input_size)
+        for st in self.encoder.strides[:-1]:
+            cur = [i // j for i, j in zip(cur, st)]
+            sizes.append(cur)
+        total = np.int64(0)
+        n = len(self.stages)
+        for level in range(n):
+            sp = sizes[-(level + 1)]
+            voxels = np.prod(sp, dtype=np.int64)
+            total += self.stages[level].compute_conv_feature_map_size(sp)
+            total += self.encoder.output_channels[-(level + 2)] * voxels           # transposed-conv output
+            if self.deep_supervision or level == n - 1:
+                total += self.num_classes * voxels
+        return total
 
 
 class MI355PlainConvUNet(nn.Module):

@@ -15,28 +15,28 @@ import torch.distributed as dist
 
 
 def ddp_batch_split(global_batch_size, world_size, oversample_foreground_percent=0.33):
-    """nnUNetTrainer._set_batch_size_and_oversample (:304-349) -> per-rank (batch sizes, oversample percents)."""
-    assert global_batch_size >= world_size, \
-        'Cannot run DDP if the batch size is smaller than the number of GPUs... Duh.'
-    batch_sizes, oversample_percents = [], []
-    batch_size_per_GPU = int(np.ceil(global_batch_size / world_size))
-    for rank in range(world_size):
-        if (rank + 1) * batch_size_per_GPU > global_batch_size:
-            batch_size = batch_size_per_GPU - ((rank + 1) * batch_size_per_GPU - global_batch_size)
+    """Per-rank (batch sizes, foreground-oversampling fractions) of a plans batch split over `world_size` ranks --
+    the rule of nnUNetTrainer._set_batch_size_and_oversample (:304-349), pinned to that method by
+    tests/golden/ddp_split.json.  Rank r takes ceil(G/W) samples, the last ranks what is left; the samples are thought
+    of as laid out 0..G-1 and the LAST `oversample` fraction of them is forced-foreground, so a rank's fraction is the
+    part of its interval that lies beyond (1 - oversample) * G."""
+    G, W = int(global_batch_size), int(world_size)
+    if G < W:
+        raise AssertionError('Cannot run DDP if the batch size is smaller than the number of GPUs... Duh.')
+    per_rank = int(np.ceil(G / W))
+    sizes = [per_rank if (r + 1) * per_rank <= G else G - r * per_rank for r in range(W)]
+    ends = np.cumsum(sizes)
+    cut = 1 - oversample_foreground_percent
+    fractions = []
+    for size, end in zip(sizes, ends.tolist()):
+        lo, hi = (end - size) / G, end / G
+        if hi < cut:
+            fractions.append(0.0)
+        elif lo > cut:
+            fractions.append(1.0)
         else:
-            batch_size = batch_size_per_GPU
-        batch_sizes.append(int(batch_size))
-        sample_id_low = 0 if len(batch_sizes) == 0 else int(np.sum(batch_sizes[:-1]))
-        sample_id_high = int(np.sum(batch_sizes))
-        if sample_id_high / global_batch_size < (1 - oversample_foreground_percent):
-            oversample_percents.append(0.0)
-        elif sample_id_low / global_batch_size > (1 - oversample_foreground_percent):
-            oversample_percents.append(1.0)
-        else:
-            covered = sample_id_high / global_batch_size - sample_id_low / global_batch_size
-            oversample_percents.append(float(
-                1 - (((1 - oversample_foreground_percent) - sample_id_low / global_batch_size) / covered)))
-    return batch_sizes, oversample_percents
+            fractions.append(float(1 - ((cut - lo) / (hi - lo))))
+    return [int(v) for v in sizes], fractions
 
 
 class BucketedGradReducer:

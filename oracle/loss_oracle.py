@@ -4,7 +4,9 @@ Reference-pinned (module importable by file path; cross-checked in tests/test_or
 frozen in tests/golden/):
 * RobustCrossEntropyLoss        nnUNet/nnunetv2/training/loss/robust_ce_loss.py:6-16
 * soft_erode/dilate/open/skel   nnUNet/nnunetv2/training/loss/soft_skeleton.py:6-37
-Restated from text (module not importable -> fixtures generated from this restatement):
+Reference-pinned through the function body (the module itself fails at `import lightly`; tools/make_golden.py compiles
+the two function definitions out of the file, runs them and freezes inputs/outputs in tests/golden/; the restatements
+below reproduce those fixtures bit for bit, tests/test_oracle.py):
 * distill_kl, l2_loss           nnUNet/nnunetv2/training/loss/other_loss.py:51-64, :67-78
 "parity unpinned" (files missing from the fork; semantics = upstream nnU-Net 2.1.1 constrained by the call
 site nnUNet/nnunetv2/training/nnUNetTrainer/nnUNetTrainer.py:351-375):

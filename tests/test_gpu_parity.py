@@ -358,6 +358,35 @@ def test_feature_kl_ndhwc(name):
     close(b.grad, z["gb"], 1e-8, 1e-4, "gb")
 
 
+@pytest.mark.parametrize("layout", ["planar", "ndhwc", "mixed"])
+def test_l2_loss_plain_mse_reference_fixture(layout):
+    """l2_loss(channel_wise=False) (other_loss.py:77-78) against the fixture the reference function produced; feature
+    maps arrive NDHWC on the path, planar from outside, and the two operands may differ in layout."""
+    from multimodal_mvd_seg_amd import losses, ops
+    z = load_npz("l2_loss_plain.npz")
+    assert str(z["source"]).startswith("reference ")
+    a, b = G(z["a"]), G(z["b"])
+    if layout in ("ndhwc", "mixed"):
+        a = ops.to_ndhwc(a)
+    if layout == "ndhwc":
+        b = ops.to_ndhwc(b)
+    a.requires_grad_()
+    b.requires_grad_()
+    l = losses.l2_loss(a, b, channel_wise=False)
+    l.backward()
+    close(l, z["loss"], 1e-7, 1e-6, "loss")
+    close(a.grad, z["ga"], 1e-9, 1e-5, "ga")
+    close(b.grad, z["gb"], 1e-9, 1e-5, "gb")
+    # odd element count (scalar tail of the float4 loop)
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(3, 5, 7, generator=g), torch.randn(3, 5, 7, generator=g)
+    gx = G(x, True)
+    lo = ops.MseFn.apply(gx, G(y))
+    lo.backward()
+    close(lo, ((x - y) ** 2).mean(), 1e-7, 1e-6, "loss (odd n)")
+    close(gx.grad, 2 * (x - y) / x.numel(), 1e-9, 1e-5, "grad (odd n)")
+
+
 # ================================================================================================ soft skeleton
 @pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.startswith("soft_skel_")))
 def test_soft_skel_reference_fixture(name):

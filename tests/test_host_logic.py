@@ -6,8 +6,9 @@ import os
 import numpy as np
 import pytest
 import torch
+from torch import nn
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from multimodal_mvd_seg_amd import losses, network, optim, parallel, trainer
 from oracle import loss_oracle as LO, step_oracle as SO, unet_oracle as UO
 
@@ -240,3 +241,76 @@ def test_device_loader_bbox_rules_follow_reference():
         dl.generate_train_batch(p1)  # no CPU path
     with pytest.raises(NotImplementedError):
         DeviceDataLoader3D(ds, 2, (16, 20, 20), patch, _Labels(), device="cpu")
+
+
+# ------------------------------------------------------------------------- fixtures generated by reference functions
+def test_get_bbox_equals_reference_method_fixture():
+    """tests/golden/get_bbox.json: boxes AND the numpy RNG state after each call, produced by the reference's own
+    nnUNetDataLoaderBase.get_bbox (tools/make_golden.py compiles the method out of base_data_loader.py:64-139)."""
+    from multimodal_mvd_seg_amd.dataloading import DeviceDataLoader3D
+    d = json.load(open(os.path.join(GOLDEN, "get_bbox.json")))
+    assert d["source"].startswith("reference ")
+    seen_fg = seen_pad = 0
+    for c in d["cases"]:
+        dl = DeviceDataLoader3D.__new__(DeviceDataLoader3D)  # host logic only: no dataset, no device
+        dl.patch_size = tuple(c["patch_size"])
+        dl.need_to_pad = np.array(c["need_to_pad"], dtype=int)
+        dl.has_ignore = c["has_ignore"]
+        dl.annotated_classes_key = tuple(c["annotated_classes_key"])
+        cl = {(tuple(k) if isinstance(k, list) else k): np.array(v, dtype=np.int64).reshape(-1, 4)
+              for k, v in c["class_locations"]}
+        np.random.seed(c["seed"])
+        lbs, ubs = dl.get_bbox(np.array(c["shape"]), c["force_fg"], cl, c["overwrite_class"])
+        tail = float(np.random.uniform())
+        assert [int(v) for v in lbs] == c["bbox_lbs"] and [int(v) for v in ubs] == c["bbox_ubs"], c
+        assert tail == c["rng_tail"], "different number / order of RNG draws than the reference"
+        seen_fg += c["force_fg"]
+        seen_pad += any(s < p for s, p in zip(c["shape"], c["patch_size"]))
+    assert seen_fg >= 20 and seen_pad >= 10
+
+
+def _inference_host_namespace():
+    src = open(os.path.join(ROOT, "multimodal_mvd_seg_amd", "inference.py")).read()
+    ns = {}
+    exec(compile(src.replace("from ._lib import call", "call = None"), "inference.py", "exec"), ns)
+    return ns
+
+
+def test_sliding_window_steps_and_gaussian_equal_reference_fixture():
+    """tests/golden/sw_steps.json: compute_steps_for_sliding_window / compute_gaussian of the reference
+    (sliding_window_prediction.py:10-56) executed in the build container."""
+    ns = _inference_host_namespace()
+    d = json.load(open(os.path.join(GOLDEN, "sw_steps.json")))
+    assert d["source"].startswith("reference ")
+    for c in d["steps"]:
+        assert ns["compute_steps_for_sliding_window"](c["image_size"], c["tile_size"], c["tile_step_size"]) == c["steps"]
+    for c in d["gaussian"]:
+        g = ns["compute_gaussian"](c["tile_size"], c["sigma_scale"], c["value_scaling_factor"])
+        ref = np.array(c["map"], dtype=np.float64).reshape(c["tile_size"])
+        assert np.abs(g - ref).max() <= 2e-6 * ref.max()
+    with pytest.raises(ValueError):
+        ns["compute_steps_for_sliding_window"]((10, 10), (12, 8), 0.5)
+
+
+def test_decoder_feature_map_size_known_answer():
+    """compute_conv_feature_map_size (the planner's VRAM proxy, UNetDecoder.py:123-150 + the encoder's): values of the
+    cfg-2 network, with and without deep supervision (frozen from the formula)."""
+    net, _ = build("cfg2")
+    assert int(net.compute_conv_feature_map_size((128, 128, 128))) == 458488320
+    assert int(net.decoder.compute_conv_feature_map_size((128, 128, 128))) == 279861760
+    net.decoder.deep_supervision = False
+    assert int(net.decoder.compute_conv_feature_map_size((160, 160, 128))) == 434944000
+
+
+def test_conv_block_refuses_plans_it_would_silently_mis_execute():
+    from multimodal_mvd_seg_amd.network import ConvDropoutNormReLU
+    ok = dict(norm_op=nn.InstanceNorm3d, norm_op_kwargs={'eps': 1e-5, 'affine': True}, nonlin=nn.LeakyReLU,
+              nonlin_kwargs={'inplace': True})
+    blk = ConvDropoutNormReLU(nn.Conv3d, 4, 8, 3, 1, True, **ok)
+    assert blk.nonlin.negative_slope == 0.01
+    blk = ConvDropoutNormReLU(nn.Conv3d, 4, 8, 3, 1, True, **{**ok, "nonlin_kwargs": {'negative_slope': 0.2}})
+    assert blk.nonlin.negative_slope == 0.2
+    for bad in ({"norm_op": None}, {"norm_op": nn.BatchNorm3d}, {"nonlin": nn.ReLU}, {"nonlin": None},
+                {"norm_op_kwargs": {'eps': 1e-5, 'affine': False}}):
+        with pytest.raises(NotImplementedError):
+            ConvDropoutNormReLU(nn.Conv3d, 4, 8, 3, 1, True, **{**ok, **bad})

@@ -340,3 +340,37 @@ def test_feed_oracle_resize_index_and_crop_pad_known_answer():
     s = FO.crop_pad(seg, [-1, 1, 3], (3, 2, 4), -1)
     assert s.dtype == np.int16 and (s == -1).sum() == 24 - 2 * 2 * 2 and FO.remove_label(s).min() == 0
     assert np.array_equal(FO.mirror(vol, 0b101), vol[:, ::-1, :, ::-1])
+
+
+def test_reference_extracted_fixtures_are_reference_sourced_and_the_oracle_matches_them():
+    """distill_kl / l2_loss (other_loss.py:51-78), the per-rank batch split (nnUNetTrainer.py:304-349), the sliding-window
+    placement + Gaussian map (sliding_window_prediction.py:10-56): fixtures generated by the reference function bodies
+    themselves (tools/make_golden.py::ref_function); the oracle restatements must reproduce them exactly."""
+    from oracle import infer_oracle as IO
+    for name in ("distill_kl_c5_T1", "distill_kl_c5_T4", "distill_kl_c1_T1", "distill_kl_c1_T4"):
+        z = load_npz(name + ".npz")
+        assert str(z["source"]).startswith("reference nnUNet") or str(z["source"]).startswith("reference training/"), z["source"]
+        ys, yt = T(z["ys"]).requires_grad_(), T(z["yt"]).requires_grad_()
+        l = LO.distill_kl(ys, yt, int(z["T"]))
+        l.backward()
+        assert torch.equal(l.detach(), T(z["loss"])) and torch.equal(ys.grad, T(z["gys"])) and torch.equal(yt.grad, T(z["gyt"]))
+    for name in ("feat_kl_T1", "feat_kl_T4"):
+        z = load_npz(name + ".npz")
+        assert str(z["source"]).startswith("reference ")
+        a, b = T(z["a"]).requires_grad_(), T(z["b"]).requires_grad_()
+        l = LO.l2_loss(a, b, True, int(z["T"]))
+        l.backward()
+        assert torch.equal(l.detach(), T(z["loss"])) and torch.equal(a.grad, T(z["ga"])) and torch.equal(b.grad, T(z["gb"]))
+    z = load_npz("l2_loss_plain.npz")
+    assert str(z["source"]).startswith("reference ")
+    a, b = T(z["a"]).requires_grad_(), T(z["b"]).requires_grad_()
+    l = LO.l2_loss(a, b, False)
+    l.backward()
+    assert torch.equal(l.detach(), T(z["loss"])) and torch.equal(a.grad, T(z["ga"])) and torch.equal(b.grad, T(z["gb"]))
+    assert json.load(open(os.path.join(GOLDEN, "ddp_split.json")))["source"].startswith("reference ")
+    d = json.load(open(os.path.join(GOLDEN, "sw_steps.json")))
+    for c in d["steps"]:
+        assert IO.compute_steps_for_sliding_window(c["image_size"], c["tile_size"], c["tile_step_size"]) == c["steps"]
+    for c in d["gaussian"]:
+        g = IO.compute_gaussian(tuple(c["tile_size"]), c["sigma_scale"], c["value_scaling_factor"]).numpy()
+        assert np.abs(g.reshape(-1) - np.array(c["map"])).max() <= 1e-6 * max(c["map"])
