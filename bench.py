@@ -22,11 +22,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-METRIC = "train-step samples/sec on 4-modality 128^3 patches (PlainConvUNet 3d_fullres, fp32)"
+
+
+def metric_name(config, precision, patch):
+    """BASELINE.json's metric, qualified by what was actually run (dtype and configuration follow the flags)."""
+    what = {"cfg2": "PlainConvUNet 3d_fullres", "cfg3": "PlainConvUNet 3d_fullres, mutual-distillation dual branch",
+            "cfg4": "PlainConvUNet 3d_fullres, mutual-distillation dual branch + soft-clDice topology term",
+            "cfg5": "PlainConvUNet 3d_fullres"}[config]
+    size = "128^3" if tuple(patch) == PATCH else "x".join(map(str, patch))
+    return f"train-step samples/sec on 4-modality {size} patches ({what}, {'fp32' if precision == 'fp32' else 'bf16 mixed precision'})"
+
+
 PATCH = (128, 128, 128)
 STRIDES = [[1, 1, 1]] + [[2, 2, 2]] * 5
 IN_CH, NUM_CLASSES, PER_GPU_BATCH = 4, 5, 2
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -48,13 +59,67 @@ def time_kernel(fn, iters, torch):
     return e0.elapsed_time(e1) / iters
 
 
-def measured_traffic():
+def measured_traffic(key="traffic_bytes_per_launch"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in their own runs, gfx950 half-count correction applied): profiles/r01_pmc_traffic.json."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    WRITE_SIZE in their own runs, gfx950 half-count correction applied): the newest profiles/rNN_pmc_traffic.json
+    that holds `key`."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            v = json.load(open(path)).get(key)
+        except (OSError, ValueError):
+            continue
+        if v is not None:
+            return v
+    return None
+
+
+def bf16_block_roofline(torch, dev, patch):
+    """bf16 mixed precision (BASELINE configs[3], [4]): the fused conv block of the north_star's HBM target, conv3d
+    32 -> 32 at the full patch, batch 2, bf16 activations, through the entry point ops.Conv3dFn calls.
+    ALGORITHMIC bytes = (C_in*N_in + C_out*N_out) * 2 B: read the producer's output once, write the raw
+    conv output once.  `bound` = hbm (block arithmetic intensity 432 flop/B vs a ridge of ~312); the MFMA view is given
+    beside it."""
+    from multimodal_mvd_seg_amd import ops
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    import ctypes
+    N, C, K = PER_GPU_BATCH, 32, 32
+    D, H, W = patch
+    x = ops.empty_cl3d((N, C, D, H, W), dev, torch.bfloat16).normal_()
+    w = torch.randn(K, C, 3, 3, 3, device=dev) * 0.05
+    bias = torch.zeros(K, device=dev)
+    wf, _ = ops.pack_weight_bf16(w, False)
+    y = ops.empty_cl3d((N, K, D, H, W), dev, torch.bfloat16)
+    ws = torch.empty(max(1, query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K)), dtype=torch.uint8, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def conv():
+        call("mvd_conv3d_fwd_bf16", P(x), C, None, 0, P(wf), P(bias), P(y), N, D, H, W, K, i3((3, 3, 3)), i3((1, 1, 1)),
+             P(ws), ws.numel(), s)
+    ms = time_kernel(conv, 10, torch)
+    V = float(N * D * H * W)
+    alg_bytes = (C + K) * V * 2.0
+    flops = 2.0 * 27 * C * K * V
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    roof = {"kernel": f"conv3d_fwd 32->32 @{'x'.join(map(str, patch))} bf16 (fwd-type implicit GEMM on "
+                      "v_mfma_f32_32x32x16_bf16, weights resident in LDS: k_fwd16p)",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_GB_per_launch": round(alg_bytes / 1e9, 4),
+            "traffic": measured_traffic("traffic_bytes_per_launch_bf16"), "ms_per_launch": round(ms, 4),
+            "mfma_view": {"tflops": round(flops / (ms * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                          "frac": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}}
+    g, b = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+
+    def norm():
+        ops.InstanceNormLeakyReLUFn.apply(y, g, b, 1e-5, 0.01)
+    nms = time_kernel(norm, 10, torch)
+    nbytes = 3.0 * K * V * 2
+    ngb = nbytes / (nms * 1e-3) / 1e9
+    roof["instnorm_lrelu_fwd"] = {"bound": "hbm", "achieved": round(ngb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ngb / HBM_PEAK_GBS, 4), "ms_per_launch": round(nms, 4),
+                                  "algorithmic_bytes": "3*C*N*2 (bf16 in, bf16 out)"}
+    return roof
 
 
 def dominant_kernel_roofline(torch, dev):
@@ -95,13 +160,16 @@ def dominant_kernel_roofline(torch, dev):
     exec_ratio = {0: 1.0, 1: 2.0 / 3.0, 2: 4.0 / 9.0}[mode]
     exec_tf = conv_tf * exec_ratio
     alg_bytes = ((C1 + C2) + K) * N * D * H * W * 4.0
+    # `achieved` / `frac` price what the MFMA pipe EXECUTED (a fraction of a roofline cannot exceed 1); the direct-conv
+    # (algorithmic) rate the Winograd kernel delivers is reported beside it as `effective_tflops`
     roof = {"kernel": "conv3d_fwd 64->32 @128^3 (fwd-type implicit GEMM, " +
                       {0: "direct: k_fwd32)", 1: "Winograd F(2,3) along W: k_fwd_wino)",
                        2: "Winograd F(2x2,3x3) over H,W: k_fwd_wino2)"}[mode],
-            "bound": "mfma", "achieved": round(conv_tf, 2),
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-            "executed_flop_ratio": round(exec_ratio, 4), "executed_tflops": round(exec_tf, 2),
-            "mfma_frac_executed": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "bound": "mfma", "achieved": round(exec_tf, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(exec_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "executed_flop_ratio": round(exec_ratio, 4), "effective_tflops": round(conv_tf, 2),
+            "effective_over_peak": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
             "traffic": measured_traffic(), "ms_per_launch": round(ms, 3),
             "hbm_view": {"algorithmic_GB": round(alg_bytes / 1e9, 3),
                          "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
@@ -177,8 +245,11 @@ def cpu_baseline(torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="profiling aid: only the isolated launches of the roofline kernels (rocprofv3 --kernel-trace then "
+                         "shows the timed layer alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--patch", type=int, nargs=3, default=list(PATCH), help="debug only; the metric is quoted at 128^3")
@@ -214,6 +285,15 @@ def main():
 
     from multimodal_mvd_seg_amd import trainer
     patch = tuple(args.patch)
+
+    def roofline():
+        return bf16_block_roofline(torch, dev, patch) if args.precision == "bf16" else dominant_kernel_roofline(torch, dev)
+
+    if args.roofline_only:
+        for _ in range(3):
+            r = roofline()
+        print(json.dumps({"roofline": r}), flush=True)
+        return
     plans = trainer.make_plans(patch, STRIDES, batch_size=PER_GPU_BATCH * world)
     if args.config in ("cfg2", "cfg5"):
         tr = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, dataset_json(), device=dev)
@@ -251,7 +331,7 @@ def main():
     out = None
     if rank == 0:
         samples = PER_GPU_BATCH * world * args.steps
-        out = {"metric": METRIC, "value": round(samples / dt, 4), "unit": "samples/s", "n_gpus": world,
+        out = {"metric": metric_name(args.config, args.precision, patch), "value": round(samples / dt, 4), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
                "data": "synthetic",
@@ -266,7 +346,7 @@ def main():
                           "parallelism": f"dp{world}"},
                "final_loss": float(last["loss"])}
         if not args.no_roofline:
-            out["roofline"] = dominant_kernel_roofline(torch, dev)
+            out["roofline"] = roofline()
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

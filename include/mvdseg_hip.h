@@ -299,12 +299,14 @@ int mvd_seg_remove_components(const int32_t *seg, const int32_t *cc_labels, cons
  * SGD(momentum, nesterov, weight decay) with global-norm clipping (K10).  Replaces
  * torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step (nnUNetTrainer.py:473-477, :918-924) on flat
  * parameter / gradient / momentum buffers of n floats.
- *   sumsq: out[0] = sum g^2 (fixed-order).  step: g *= min(1, max_norm/(sqrt(sumsq)+1e-6)) (clip_scale read from
- *   device memory: no host sync); g += wd*p; buf = first ? g : mom*buf + g; g = g + mom*buf (nesterov); p -= lr*g */
+ *   sumsq: out[0] = sum g^2 (fixed-order).  step: g *= grad_scale (1/world_size under data parallelism: the mean
+ *   DDP takes after its SUM all-reduce, nnUNetTrainer.py:220-222; 1 otherwise); g *= min(1, max_norm /
+ *   (grad_scale*sqrt(sumsq)+1e-6)) (read from device memory: no host sync); g += wd*p; buf = first ? g : mom*buf + g;
+ *   g = g + mom*buf (nesterov); p -= lr*g */
 size_t mvd_sumsq_workspace_bytes(long n);
 int mvd_grad_sumsq(const float *g, float *out, long n, void *ws, size_t ws_bytes, void *stream);
 int mvd_sgd_nesterov_step(float *p, const float *g, float *buf, const float *sumsq, long n, float lr, float momentum,
-                          float weight_decay, float max_norm, int first_step, void *stream);
+                          float weight_decay, float max_norm, float grad_scale, int first_step, void *stream);
 
 /* misc elementwise helpers used by the host glue (all fixed-order / exact) */
 int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *stream);

@@ -1862,14 +1862,17 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce_wino2(const float *__rest
 #pragma unroll
     for (int bq = 0; bq < 4; bq++) redq[q][a][bq][e] = m[bq];
     __syncthreads();
-    if (q != 0) return;  // whole waves
+    if (q == 0) {  // no wave leaves before the second barrier: every one of the 16 waves reaches both
 #pragma unroll
-    for (int bq = 0; bq < 4; bq++) m[bq] = ((redq[0][a][bq][e] + redq[1][a][bq][e]) + redq[2][a][bq][e]) + redq[3][a][bq][e];
-    // row a of M times G: (M G)_aj
-    red[a][0][e] = m[0] + 0.5 * (m[1] + m[2]);
-    red[a][1][e] = 0.5 * (m[1] - m[2]);
-    red[a][2][e] = 0.5 * (m[1] + m[2]) + m[3];
-    __syncthreads();  // the q != 0 waves have terminated: the hardware barrier only counts the four live ones
+        for (int bq = 0; bq < 4; bq++)
+            m[bq] = ((redq[0][a][bq][e] + redq[1][a][bq][e]) + redq[2][a][bq][e]) + redq[3][a][bq][e];
+        // row a of M times G: (M G)_aj
+        red[a][0][e] = m[0] + 0.5 * (m[1] + m[2]);
+        red[a][1][e] = 0.5 * (m[1] - m[2]);
+        red[a][2][e] = 0.5 * (m[1] + m[2]) + m[3];
+    }
+    __syncthreads();
+    if (q != 0) return;
     if (a != 0 || j >= nout) return;
     const long gz = j / CK, ck = j - gz * CK;
     const int c = (int)(ck / K), k = (int)(ck - (long)c * K);

@@ -21,7 +21,9 @@ __global__ void k_sumsq(const float *__restrict__ g, double *__restrict__ partia
     if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
 }
 
-__device__ inline float sgd_one(float &p, float g, float &b, float clip, float lr, float mom, float wd, int first) {
+__device__ inline float sgd_one(float &p, float g, float &b, float gscale, float clip, float lr, float mom, float wd,
+                             int first) {
+    g = g * gscale;  // data-parallel mean (1/world; exactly the separate `grad *= 1/world` pass it replaces)
     g = g * clip;
     g = g + wd * p;
     b = first ? g : (mom * b + g);
@@ -32,10 +34,10 @@ __device__ inline float sgd_one(float &p, float g, float &b, float clip, float l
 
 __global__ void k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf,
                       const float *__restrict__ sumsq, long n, float lr, float mom, float wd, float max_norm,
-                      int first) {
+                      float gscale, int first) {
     float clip = 1.0f;
     if (max_norm > 0.f) {
-        float total = sqrtf(sumsq[0]);
+        float total = sqrtf(sumsq[0]) * gscale;  // sumsq is over the un-scaled buffer
         clip = max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_
         if (clip > 1.0f) clip = 1.0f;
     }
@@ -45,17 +47,17 @@ __global__ void k_sgd(float *__restrict__ p, const float *__restrict__ g, float 
     float4 *b4 = reinterpret_cast<float4 *>(buf);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 pp = p4[i], gg = g4[i], bb = first ? make_float4(0, 0, 0, 0) : b4[i];
-        sgd_one(pp.x, gg.x, bb.x, clip, lr, mom, wd, first);
-        sgd_one(pp.y, gg.y, bb.y, clip, lr, mom, wd, first);
-        sgd_one(pp.z, gg.z, bb.z, clip, lr, mom, wd, first);
-        sgd_one(pp.w, gg.w, bb.w, clip, lr, mom, wd, first);
+        sgd_one(pp.x, gg.x, bb.x, gscale, clip, lr, mom, wd, first);
+        sgd_one(pp.y, gg.y, bb.y, gscale, clip, lr, mom, wd, first);
+        sgd_one(pp.z, gg.z, bb.z, gscale, clip, lr, mom, wd, first);
+        sgd_one(pp.w, gg.w, bb.w, gscale, clip, lr, mom, wd, first);
         p4[i] = pp;
         b4[i] = bb;
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
         long i = n4 * 4 + threadIdx.x;
         float pp = p[i], bb = first ? 0.f : buf[i];
-        sgd_one(pp, g[i], bb, clip, lr, mom, wd, first);
+        sgd_one(pp, g[i], bb, gscale, clip, lr, mom, wd, first);
         p[i] = pp;
         buf[i] = bb;
     }
@@ -87,13 +89,13 @@ int mvd_grad_sumsq(const float *g, float *out, long n, void *ws, size_t ws_bytes
 }
 
 int mvd_sgd_nesterov_step(float *p, const float *g, float *buf, const float *sumsq, long n, float lr, float momentum,
-                          float weight_decay, float max_norm, int first_step, void *stream) {
+                          float weight_decay, float max_norm, float grad_scale, int first_step, void *stream) {
     MVD_REQUIRE(p && g && buf && n > 0 && (max_norm <= 0.f || sumsq), "sgd_step: bad arguments");
     MVD_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd_step: buffers must be 16-byte aligned");
     long bx = cdiv(n / 4 + 1, 256);
     if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(k_sgd, dim3(bx), dim3(256), 0, as_stream(stream), p, g, buf, sumsq, n, lr, momentum, weight_decay,
-                       max_norm, first_step);
+                       max_norm, grad_scale, first_step);
     return check_launch("sgd_step");
 }
 }

@@ -129,26 +129,45 @@ def pack_weight(weight, transposed):
 
 # ---------------------------------------------------------------------------------------------- packed-weight cache (fp32)
 # The packed copies (wf / wb, Winograd uf / ub) of a conv weight live on the weight tensor object (`_mvd_pack`) and are
-# valid for one (optimizer epoch, tensor version) stamp: torch in-place writes bump the version, the fused optimizer --
-# which updates the flat buffer through a raw pointer -- bumps the epoch and re-packs every registered weight in ONE
-# launch (repack_all: mvd_pack_weights_batch).  A stale or missing entry is packed on the spot by the per-layer entries.
+# valid for one stamp = (pack epoch, version of the parameter, storage pointer, version of the flat buffer the parameter
+# is a view of).  torch in-place writes to the parameter or to optim.FlatParams.flat (dist.broadcast, `flat -= ...`) bump
+# a version; the fused optimizer -- which updates the flat buffer through a raw pointer -- bumps the epoch and re-packs
+# every registered weight in ONE launch (repack_all: mvd_pack_weights_batch).  A stale or missing entry is packed on the
+# spot by the per-layer entries.  The one write torch cannot see is `p.data.copy_()` / any other raw-pointer writer:
+# such code must call invalidate_packs() (FlatParams.invalidate_packs).
 _PACK_EPOCH = [0]
 _PACK_LIVE = []
 
 
+def invalidate_packs():
+    """Declare every cached packed weight stale (after a write to parameter memory that bypasses torch's version
+    counters).  The next forward re-packs per layer."""
+    _PACK_EPOCH[0] += 1
+
+
+def _check_pack_generation(saved, what):
+    """`saved` = (entry, generation at forward time).  The fp32 packs are rebuilt IN PLACE; a graph kept across a weight
+    update would silently back-propagate through the new weights (torch raises for its own saved tensors: so do we)."""
+    if saved is not None and saved[0].gen != saved[1]:
+        raise RuntimeError(f"{what}: the weights were updated (optimizer.step() or an in-place write) between the forward "
+                           "and the backward pass of this graph; the packed copies saved for backward were rebuilt")
+
+
 class _PackEntry:
-    __slots__ = ("transposed", "K", "C", "T", "wf", "wb", "uf", "ub", "stamp")
+    __slots__ = ("transposed", "K", "C", "T", "wf", "wb", "uf", "ub", "stamp", "gen")
 
 
-def _pack_stamp(w):
+def _pack_stamp(w, owner=None):
     # data_ptr: `p.data = other` swaps the storage without a version bump on the parameter object
-    return (_PACK_EPOCH[0], w._version, w.data_ptr())
+    flat = getattr(owner if owner is not None else w, "_mvd_flat", None)
+    return (_PACK_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
 
 
 def _packed(weight, transposed, want_uf=False, want_ub=False):
     w = weight.detach()
     if not w.is_contiguous():  # no cache for a strided view: pack a contiguous copy
         e = _PackEntry()
+        e.gen = 0
         e.wf, e.wb = pack_weight(weight, transposed)
         e.uf = e.ub = None
         if want_uf or want_ub:
@@ -173,6 +192,7 @@ def _packed(weight, transposed, want_uf=False, want_ub=False):
         e.wb = torch.empty((e.T, e.K, e.C), dtype=torch.float32, device=w.device)
         e.uf = e.ub = None
         e.stamp = None
+        e.gen = 0
         weight._mvd_pack = e
         if len(_PACK_LIVE) >= 4096:  # inference-only use never calls repack_all: drop dead references here
             _PACK_LIVE[:] = [r for r in _PACK_LIVE if r() is not None]
@@ -186,10 +206,11 @@ def _packed(weight, transposed, want_uf=False, want_ub=False):
         if want_ub and e.ub is None:
             e.ub = torch.empty((n,), dtype=torch.float32, device=w.device)
         new_wino = True
-    if stale or e.stamp != _pack_stamp(w):
+    if stale or e.stamp != _pack_stamp(w, weight):
+        e.gen += 1  # wf / wb / uf / ub are overwritten in place
         call("mvd_pack_weight", _p(w), _p(e.wf), _p(e.wb), e.K, e.C, e.T, 1 if transposed else 0, _stream())
         new_wino = e.uf is not None or e.ub is not None
-        e.stamp = _pack_stamp(w)
+        e.stamp = _pack_stamp(w, weight)
     if new_wino:
         call("mvd_pack_weight_wino", _p(w), _p(e.uf), _p(e.ub), e.K, e.C, _stream())
     return e
@@ -207,29 +228,30 @@ def repack_all():
         alive.append(r)
         d = w.detach()
         if d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.device == e.wf.device:
-            jobs.append((d, e))
+            jobs.append((d, e, w))
     _PACK_LIVE[:] = alive
     if not jobs:
         return
-    if any(e.uf is not None or e.ub is not None for _, e in jobs) and query("mvd_wino_mode") != 2:
+    if any(e.uf is not None or e.ub is not None for _, e, _w in jobs) and query("mvd_wino_mode") != 2:
         return  # the batch entry only writes the F(2x2,3x3) layout; stale entries are packed per layer
     n = len(jobs)
     PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
     ptr = lambda t: t.data_ptr() if t is not None else None
-    w_ = PA(*[ptr(d) for d, _ in jobs])
-    wf_ = PA(*[ptr(e.wf) for _, e in jobs])
-    wb_ = PA(*[ptr(e.wb) for _, e in jobs])
-    uf_ = PA(*[ptr(e.uf) for _, e in jobs])
-    ub_ = PA(*[ptr(e.ub) for _, e in jobs])
-    K_ = IA(*[e.K for _, e in jobs])
-    C_ = IA(*[e.C for _, e in jobs])
-    T_ = IA(*[e.T for _, e in jobs])
-    tr_ = IA(*[1 if e.transposed else 0 for _, e in jobs])
+    w_ = PA(*[ptr(d) for d, _, _w in jobs])
+    wf_ = PA(*[ptr(e.wf) for _, e, _w in jobs])
+    wb_ = PA(*[ptr(e.wb) for _, e, _w in jobs])
+    uf_ = PA(*[ptr(e.uf) for _, e, _w in jobs])
+    ub_ = PA(*[ptr(e.ub) for _, e, _w in jobs])
+    K_ = IA(*[e.K for _, e, _w in jobs])
+    C_ = IA(*[e.C for _, e, _w in jobs])
+    T_ = IA(*[e.T for _, e, _w in jobs])
+    tr_ = IA(*[1 if e.transposed else 0 for _, e, _w in jobs])
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
     call("mvd_pack_weights_batch", n, cast(w_), cast(wf_), cast(wb_), cast(uf_), cast(ub_), cast(K_), cast(C_), cast(T_),
          cast(tr_), _stream())
-    for d, e in jobs:
-        e.stamp = _pack_stamp(d)
+    for d, e, w in jobs:
+        e.stamp = _pack_stamp(d, w)
+        e.gen += 1
 
 
 def pack_weight_bf16(weight, transposed):
@@ -255,8 +277,8 @@ def _packed_bf16(weight, transposed):
     if not w.is_contiguous():
         return pack_weight_bf16(weight, transposed)
     e = getattr(weight, "_mvd_pack16", None)
-    if e is None or e[0] != (_pack_stamp(w), transposed, w.device):
-        e = ((_pack_stamp(w), transposed, w.device),) + tuple(pack_weight_bf16(weight, transposed))
+    if e is None or e[0] != (_pack_stamp(w, weight), transposed, w.device):
+        e = ((_pack_stamp(w, weight), transposed, w.device),) + tuple(pack_weight_bf16(weight, transposed))
         weight._mvd_pack16 = e
     return e[1], e[2]
 
@@ -317,6 +339,7 @@ class Conv3dFn(Function):
                      i3(stride), _p(ws), ws.numel(), _stream())
         ctx.bf = bf
         ctx.params = (weight, bias)
+        ctx.pack = None if bf else (pk, pk.gen)
         ctx.save_for_backward(x1, x2, wb, ub)
         ctx.geom = (N, C1, C2, D, H, W, K, ks, tuple(stride), tuple(od), bias is not None)
         return y
@@ -325,6 +348,7 @@ class Conv3dFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x1, x2, wb, ub = ctx.saved_tensors
+        _check_pack_generation(ctx.pack, "conv3d backward")  # (the bf16 packs are fresh tensors per stamp)
         N, C1, C2, D, H, W, K, ks, stride, od, has_bias = ctx.geom
         dy = to_ndhwc(dy)
         dev = dy.device
@@ -383,6 +407,7 @@ class ConvTranspose3dFn(Function):
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K), x.device)
         ctx.bf = bf
         ctx.params = (weight, bias)
+        ctx.pack = None if bf else (pk, pk.gen)
         call("mvd_convT3d_fwd_bf16" if bf else "mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
              _stream())
         ctx.save_for_backward(x, wb)
@@ -393,6 +418,7 @@ class ConvTranspose3dFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, wb = ctx.saved_tensors
+        _check_pack_generation(ctx.pack, "convT3d backward")
         N, C, K, D, H, W, stride, has_bias = ctx.geom
         dy = to_ndhwc(dy)
         dev = dy.device

@@ -48,7 +48,13 @@ class FlatParams:
                 view = self.flat[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
+                p._mvd_flat = self.flat   # ops' packed-weight cache also watches the flat buffer's version counter
         self.attach_grads()
+
+    def invalidate_packs(self):
+        """Call after writing parameter memory behind torch's back (`p.data.copy_()`, a raw-pointer kernel): the
+        packed weight copies the conv kernels read are rebuilt at the next forward."""
+        ops.invalidate_packs()
 
     def attach_grads(self):
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
@@ -91,6 +97,9 @@ class FusedSGDNesterov:
         self.momentum_buffer = torch.zeros_like(self.fp.flat)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._steps = 0
+        # data parallel: the all-reduce leaves the SUM over ranks in fp.grad; the mean (DDP semantics) is taken inside
+        # the optimizer kernel (g * grad_scale) instead of one more pass over the gradient buffer
+        self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=True):
         # the reference passes set_to_none=True (nnUNetTrainer.py:901); flat gradient views must persist, so zero
@@ -98,7 +107,7 @@ class FusedSGDNesterov:
 
     def grad_norm(self):
         """Device scalar: the global gradient 2-norm of the last step (before clipping)."""
-        return self.sumsq.sqrt()
+        return self.sumsq.sqrt() * self.grad_scale
 
     def step(self):
         fp, g = self.fp, self.param_groups[0]
@@ -112,7 +121,7 @@ class FusedSGDNesterov:
         if self.max_grad_norm and self.max_grad_norm > 0:
             call("mvd_grad_sumsq", P(fp.grad), P(self.sumsq), n, P(ws), ws.numel(), s)
         call("mvd_sgd_nesterov_step", P(fp.flat), P(fp.grad), P(self.momentum_buffer), P(self.sumsq), n, float(g['lr']),
-             float(g['momentum']), float(g['weight_decay']), float(self.max_grad_norm or 0.0),
+             float(g['momentum']), float(g['weight_decay']), float(self.max_grad_norm or 0.0), float(self.grad_scale),
              1 if self._steps == 0 else 0, s)
         self._steps += 1
         # the update went through a raw pointer: new weight epoch + every cached packed weight rebuilt in one launch

@@ -39,13 +39,49 @@ def ddp_batch_split(global_batch_size, world_size, oversample_foreground_percent
     return [int(v) for v in sizes], fractions
 
 
-class BucketedGradReducer:
-    """Bucketed, overlapped gradient all-reduce over a FlatParams gradient buffer."""
+_HOOK_ON_UNDEFINED = []
 
-    def __init__(self, flat_params, bucket_bytes=25 * 1024 * 1024, process_group=None):
+
+def _hook_fires_for_undefined_grad():
+    """Does autograd run a leaf's post-accumulate-grad hook when the producing Function returned None for it?  (It does
+    in torch 2.x: the AccumulateGrad node executes once ALL uses of the parameter in the graph have run, defined
+    gradient or not.)  Probed once on a 1-element CPU graph rather than assumed."""
+    if not _HOOK_ON_UNDEFINED:
+        class _Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, dy):
+                return dy, None
+        w = torch.nn.Parameter(torch.zeros(1))
+        fired = []
+        h = w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+        _Probe.apply(torch.ones(1, requires_grad=True), w).sum().backward()
+        h.remove()
+        _HOOK_ON_UNDEFINED.append(bool(fired))
+    return _HOOK_ON_UNDEFINED[0]
+
+
+class BucketedGradReducer:
+    """Bucketed, overlapped gradient all-reduce over a FlatParams gradient buffer.
+
+    A bucket is launched when every one of its parameters has reported its gradient complete.  The report is the
+    parameter's post-accumulate-grad hook: autograd runs it once per backward pass, after EVERY use of the parameter in
+    the graph has executed -- also when the HIP backward kernel wrote the gradient straight into the flat buffer
+    (optim.FlatParams' direct sink) and handed autograd None.  (Round 1 counted the sink's own listener as a second
+    report: every parameter reported twice and buckets were launched half-filled.)  Only if the running torch does not
+    fire the hook for undefined gradients (probed at construction) is the sink listener used as well, idempotently.
+    A report for a bucket whose all-reduce is already in flight -- a second backward() before wait() -- raises
+    instead of dropping the late gradient.  `optimizer` (FusedSGDNesterov) receives grad_scale = 1/world so that the
+    mean is taken inside the optimizer kernel."""
+
+    def __init__(self, flat_params, bucket_bytes=25 * 1024 * 1024, process_group=None, optimizer=None):
         self.fp = flat_params
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.optimizer = optimizer
         # buckets in reverse parameter order (backward completion order), each a contiguous slice of fp.grad
         n = len(self.fp.params)
         ends = [o + ((p.numel() + self.fp.ALIGN - 1) // self.fp.ALIGN) * self.fp.ALIGN
@@ -62,27 +98,35 @@ class BucketedGradReducer:
         for b, (_, _, idx) in enumerate(self.buckets):
             for i in idx:
                 self.bucket_of[i] = b
-        self._pending = [0] * len(self.buckets)
-        self._works = []
         self._hooks = []
         if self.world > 1:
             for i, p in enumerate(self.fp.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
-            # gradients the HIP kernels write straight into the flat buffer never pass through autograd's accumulation
+            self.uses_listener = not _hook_fires_for_undefined_grad()
             listeners = getattr(self.fp, 'listeners', None)
-            if listeners is not None:
+            if self.uses_listener and listeners is not None:
                 listeners.append(self._on_ready)
+            if optimizer is not None:
+                optimizer.grad_scale = 1.0 / self.world
         self.reset()
 
     def reset(self):
-        self._pending = [len(idx) for (_, _, idx) in self.buckets]
+        self._ready = set()
+        self._missing = [len(idx) for (_, _, idx) in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
 
     def _on_ready(self, i):
         b = self.bucket_of[i]
-        self._pending[b] -= 1
-        if self._pending[b] == 0 and not self._launched[b]:
+        if self._launched[b]:
+            raise RuntimeError(
+                f"gradient of parameter #{i} arrived after its bucket's all-reduce was launched (a second backward() "
+                "before reducer.wait()?): it would not be reduced.  Accumulate locally and reduce once per step.")
+        if i in self._ready:
+            return
+        self._ready.add(i)
+        self._missing[b] -= 1
+        if self._missing[b] == 0:
             self._launch(b)
 
     def _make_hook(self, i):
@@ -100,22 +144,29 @@ class BucketedGradReducer:
         self._works.append((work, buf))
 
     def wait(self):
-        """Call after backward: launches whatever bucket did not fire (parameters without gradient), fences the
-        collectives and averages (DDP semantics: gradient = mean over ranks)."""
+        """Call after backward: launches whatever bucket did not fire (parameters without gradient this step), fences
+        the collectives and takes the mean over ranks (DDP semantics) -- inside the optimizer kernel when an optimizer
+        was given, else with one scaling pass."""
         if self.world <= 1:
             return
         for b in range(len(self.buckets)):
-            if not self._launched[b]:  # parameters without a gradient this step (or counted twice): reduce now
+            if not self._launched[b]:
                 self._launch(b)
         for work, _ in self._works:
             work.wait()
-        self.fp.grad.mul_(1.0 / self.world)
+        if self.optimizer is None:
+            self.fp.grad.mul_(1.0 / self.world)
         self.reset()
 
     def remove_hooks(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        listeners = getattr(self.fp, 'listeners', None)
+        if listeners is not None and self._on_ready in listeners:
+            listeners.remove(self._on_ready)
+        if self.optimizer is not None:
+            self.optimizer.grad_scale = 1.0
 
 
 def gather_dice_stats(stats):
@@ -132,3 +183,5 @@ def broadcast_parameters(flat_params, src=0):
     """DDP broadcasts rank 0's parameters at wrap time (nnUNetTrainer.py:222)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(flat_params.flat, src=src)
+        if hasattr(flat_params, "invalidate_packs"):
+            flat_params.invalidate_packs()  # packed weight copies made before the broadcast are stale now

@@ -174,7 +174,7 @@ class nnUNetTrainerMI355(object):
         if self.is_ddp:
             # DDP(network): broadcast rank 0's weights, then reduce gradients bucket-wise during backward (:220-222)
             broadcast_parameters(self.optimizer.fp)
-            self.reducer = BucketedGradReducer(self.optimizer.fp)
+            self.reducer = BucketedGradReducer(self.optimizer.fp, optimizer=self.optimizer)
         self.loss = self._build_loss()
         self._set_batch_size_and_oversample()
         self.was_initialized = True

@@ -464,6 +464,84 @@ def test_fused_sgd_matches_torch_sgd_with_clipping():
             close(q, p.detach(), 1e-6, 1e-6, f"param step {step}")
 
 
+def test_fused_sgd_grad_scale_is_the_data_parallel_mean():
+    """grad_scale = 1/world inside the optimizer kernel == `grad *= 1/world` followed by the unscaled step (what DDP's
+    SUM all-reduce + division does, nnUNetTrainer.py:220-222), including the clipping decision."""
+    from multimodal_mvd_seg_amd import optim
+    torch.manual_seed(1)
+    base = [torch.randn(s) for s in [(40, 9, 3), (7,), (515,)]]
+    for gmag in (40.0, 0.02):
+        a = [torch.nn.Parameter(p.clone().to(DEV)) for p in base]
+        b = [torch.nn.Parameter(p.clone().to(DEV)) for p in base]
+        oa = optim.FusedSGDNesterov(a, 1e-2, weight_decay=3e-5, momentum=0.99, max_grad_norm=12)
+        ob = optim.FusedSGDNesterov(b, 1e-2, weight_decay=3e-5, momentum=0.99, max_grad_norm=12)
+        oa.grad_scale = 0.25
+        for step in range(3):
+            oa.zero_grad()
+            ob.zero_grad()
+            for p, q in zip(a, b):
+                g = (torch.randn(p.shape) * gmag).to(DEV)
+                p.grad.copy_(g)            # the SUM over 4 ranks
+                q.grad.copy_(g * 0.25)     # the mean, taken by a separate pass
+            oa.step()
+            ob.step()
+            assert abs(float(oa.grad_norm()) - float(ob.grad_norm())) <= 1e-6 * float(ob.grad_norm())
+            for p, q in zip(a, b):
+                close(p, q.detach().cpu(), 1e-7, 1e-6, f"param step {step}")
+
+
+def test_packed_weight_cache_sees_every_torch_visible_write_and_guards_saved_packs():
+    """the packed copies the conv kernels read must follow writes through the flat buffer (dist.broadcast,
+    `flat -= ...`), through the parameter, and declared raw writes; a graph kept across optimizer.step() must not
+    back-propagate through rebuilt packs silently."""
+    from multimodal_mvd_seg_amd import network, ops, optim
+    from torch import nn
+    torch.manual_seed(0)
+    conv = network.HipConv3d(32, 32, 3, 1, padding=1, bias=True).to(DEV)
+    tconv = network.HipConvTranspose3d(32, 32, 2, 2, bias=True).to(DEV)
+    fp = optim.FlatParams(list(conv.parameters()) + list(tconv.parameters()))
+    x = torch.randn(1, 32, 8, 8, 16, device=DEV)
+
+    def fresh():
+        c2 = network.HipConv3d(32, 32, 3, 1, padding=1, bias=True).to(DEV)
+        t2 = network.HipConvTranspose3d(32, 32, 2, 2, bias=True).to(DEV)
+        c2.load_state_dict(conv.state_dict())
+        t2.load_state_dict(tconv.state_dict())
+        with torch.no_grad():
+            return c2(x), t2(x)
+
+    def check(what):
+        with torch.no_grad():
+            y, t = conv(x), tconv(x)
+        fy, ft = fresh()
+        assert torch.equal(y, fy) and torch.equal(t, ft), f"stale packed weights after {what}"
+
+    check("construction")
+    with torch.no_grad():
+        fp.flat.mul_(1.5)                      # in-place write through the flat buffer (what dist.broadcast does)
+    check("an in-place write to FlatParams.flat")
+    with torch.no_grad():
+        conv.weight.add_(0.01)                 # write through the parameter
+        tconv.weight.mul_(0.5)
+    check("an in-place write to the parameter")
+    conv.weight.data.copy_(conv.weight.data * 2)   # invisible to torch's version counters ...
+    fp.invalidate_packs()                          # ... so the writer declares it
+    check("p.data.copy_ + invalidate_packs()")
+    # a graph kept across an optimizer step
+    opt = optim.FusedSGDNesterov(fp, 1e-2)
+    xg = x.clone().requires_grad_()
+    y = conv(xg)
+    opt.zero_grad()
+    fp.grad.normal_()
+    opt.step()                                  # rebuilds every cached pack in place
+    with pytest.raises(RuntimeError, match="weights were updated"):
+        y.sum().backward()
+    check("optimizer.step()")
+    y = conv(xg)                                # a fresh graph is fine
+    y.sum().backward()
+    assert xg.grad is not None
+
+
 # ================================================================================================ end to end
 def _mi355_net_from_fixture(z, in_ch, n_stages):
     from multimodal_mvd_seg_amd import network
