@@ -280,6 +280,27 @@ int mvd_cc_label(const uint8_t *mask, int32_t *labels, int32_t *count, int D, in
 /* mask[v] = (f[v] > thr) (or >= when ge != 0) */
 int mvd_threshold_mask(const float *f, uint8_t *mask, long n, float thr, int ge, void *stream);
 
+/* H0 persistence: birth / death pairing of the connected components of the sub- (sublevel != 0) or super-level sets
+ * of a scalar field f [D,H,W] on the grid graph with conn in {6, 14 (Freudenthal), 26}.  Replaces, for maxdim 0, the
+ * CPU persistence of the vendored TopologyLayer C++: lower-star extension complex.cpp:136-146, filtration order
+ * complex.cpp:182-196, reduction hom.cpp:51-69 (== union-find with the elder rule on vertices + edges), one bar per
+ * vertex hom.cpp:155-185, called from functional/sublevel.py:21-49 / nn/levelset.py:137-163 after a D2H copy.
+ *   device (mvd_h0_sorted_edges): keys_sorted[e] = all D*H*W*n_off 64-bit edge keys, ascending:
+ *       (order-preserving bits of max(g[u], g[v])) << 32 | (v * n_off + k), g = f or -f; edges that leave the grid
+ *       carry ~0 and sort last; the first mvd_h0_num_edges() keys are the filtration order of the 1-cells.
+ *   host (mvd_h0_pair_host, plain C++): one elder-rule union-find sweep over those keys copied to host memory.
+ *       death[v] / death_vertex[v] describe the bar born at vertex v (birth value f[v]): the value at which it dies
+ *       (+inf, resp. -inf for super-level, for the essential bar of each component) and the critical (arg-max) vertex
+ *       of the killing edge (-1 for essential bars) -- the `backprop_lookup` of hom.cpp:178-183.  Returns the number
+ *       of essential bars, < 0 on error.
+ * Integer / comparison work: bit-exact against oracle/cc_oracle.c, multiset-exact against the reference C++. */
+long mvd_h0_num_edges(int D, int H, int W, int conn);
+size_t mvd_h0_workspace_bytes(int D, int H, int W, int conn);
+int mvd_h0_sorted_edges(const float *f, uint64_t *keys_sorted, int D, int H, int W, int conn, int sublevel, void *ws,
+                        size_t ws_bytes, void *stream);
+long mvd_h0_pair_host(const float *f_host, const uint64_t *keys_host, long n_edges, int D, int H, int W, int conn,
+                      int sublevel, float *death, int64_t *death_vertex);
+
 /* Connected-component post-processing of a predicted segmentation.  Replaces, on device,
  * remove_all_but_largest_component_from_segmentation (nnunetv2/postprocessing/remove_connected_components.py:22-34):
  *   mask = union over label_set of (seg == l)            -> mvd_seg_label_mask  (region_or_label_to_mask, :27-30)

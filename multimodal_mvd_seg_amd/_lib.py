@@ -104,6 +104,10 @@ SIGNATURES = {
     "mvd_dot_sum_workspace_bytes": (c_size_t, [c_long]),
     "mvd_cc_label": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_threshold_mask": (c_int, [_P, _P, c_long, c_float, c_int, _P]),
+    "mvd_h0_num_edges": (c_long, [c_int, c_int, c_int, c_int]),
+    "mvd_h0_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "mvd_h0_sorted_edges": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "mvd_h0_pair_host": (c_long, [_P, _P, c_long, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "mvd_seg_label_mask": (c_int, [_P, _P, c_long, _P, c_int, _P]),
     "mvd_cc_keep_workspace_bytes": (c_size_t, [c_long]),
     "mvd_cc_keep_largest": (c_int, [_P, c_long, c_int, _P, _P, _P]),

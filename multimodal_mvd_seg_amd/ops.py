@@ -942,6 +942,58 @@ def cc_label(mask, conn=6):
     return labels, count
 
 
+def h0_persistence(f, conn=6, sublevel=True):
+    """H0 persistence of a [D,H,W] device field: (birth [N], death [N], death_vertex [N]) as CPU tensors, one bar per
+    vertex in linear-index order (the reference's C++ also returns its diagrams on the CPU, functional/sublevel.py:26-49).
+    The filtration order of the edges comes from the device (edge keys + radix sort), the elder-rule pairing runs on
+    the host (hom.cpp:51-69 restricted to vertices and edges)."""
+    _require_cuda(f)
+    if f.dim() != 3 or f.dtype != torch.float32:
+        raise RuntimeError("h0_persistence takes a [D,H,W] float32 field")
+    x = f.detach().contiguous()
+    D, H, W = x.shape
+    ne = query("mvd_h0_num_edges", D, H, W, int(conn))
+    if ne < 0:
+        raise RuntimeError("h0_persistence: conn must be 6, 14 or 26")
+    nb = query("mvd_h0_workspace_bytes", D, H, W, int(conn))
+    ws = _Workspace.get(nb, x.device)
+    noff = {6: 3, 14: 7, 26: 13}[int(conn)]
+    keys = torch.empty((D * H * W * noff,), dtype=torch.int64, device=x.device)
+    call("mvd_h0_sorted_edges", _p(x), _p(keys), D, H, W, int(conn), int(bool(sublevel)), _p(ws), ws.numel(), _stream())
+    keys_h = keys[:ne].cpu()          # synchronises the stream
+    f_h = x.cpu()
+    death = torch.empty((D * H * W,), dtype=torch.float32)
+    dv = torch.empty((D * H * W,), dtype=torch.int64)
+    ness = _lib.load().mvd_h0_pair_host(_p(f_h), _p(keys_h), ne, D, H, W, int(conn), int(bool(sublevel)), _p(death), _p(dv))
+    if ness < 0:
+        raise RuntimeError("mvd_h0_pair_host failed: " + _lib.load().mvd_last_error().decode())
+    return f_h.reshape(-1), death, dv
+
+
+class H0DiagramFn(Function):
+    """Differentiable H0 diagram of a [D,H,W] field: returns a [N,2] CPU tensor of (birth, death) rows in vertex order,
+    essential bars with death = +-inf, like dgms[0] of persistenceForwardHom (hom.cpp:155-185).  backward is the
+    reference's persistence_backward (cohom.cpp:148-196): each finite diagram entry's gradient is added onto its critical
+    vertex (birth -> the vertex itself, death -> the arg-max vertex of the killing edge), in diagram order."""
+
+    @staticmethod
+    def forward(ctx, f, conn, sublevel):
+        birth, death, dv = h0_persistence(f, conn, sublevel)
+        ctx.save_for_backward(dv)
+        ctx.shape, ctx.device = tuple(f.shape), f.device
+        return torch.stack([birth, death], 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dv,) = ctx.saved_tensors
+        g = g.detach().cpu().float()
+        finite = dv >= 0
+        grad = g[:, 0].clone()                                          # births: one bar per vertex (every bar has one)
+        grad.index_add_(0, dv[finite], g[:, 1][finite])                 # deaths of the finite bars, in diagram order
+        return grad.view(ctx.shape).to(ctx.device), None, None
+
+
 def threshold_mask(f, thr, ge=False):
     _require_cuda(f)
     x = f.contiguous()

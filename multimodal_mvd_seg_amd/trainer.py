@@ -150,6 +150,7 @@ class nnUNetTrainerMI355(object):
         self.precision = 'fp32'
         self.loss = None
         self.reducer = None
+        self.ddp_bucket_bytes = 25 * 1024 * 1024  # DDP's default bucket_cap_mb (nnUNetTrainer.py:222 passes none)
         self.was_initialized = False
         self.batch_size = None
 
@@ -174,7 +175,7 @@ class nnUNetTrainerMI355(object):
         if self.is_ddp:
             # DDP(network): broadcast rank 0's weights, then reduce gradients bucket-wise during backward (:220-222)
             broadcast_parameters(self.optimizer.fp)
-            self.reducer = BucketedGradReducer(self.optimizer.fp, optimizer=self.optimizer)
+            self.reducer = BucketedGradReducer(self.optimizer.fp, self.ddp_bucket_bytes, optimizer=self.optimizer)
         self.loss = self._build_loss()
         self._set_batch_size_and_oversample()
         self.was_initialized = True

@@ -45,6 +45,7 @@ def main():
         torch.cuda.set_device(dev)
         torch.manual_seed(100 + rank)          # different init per rank: the DDP wrap must broadcast rank 0's weights
         tr = build_trainer(2, dev)             # GLOBAL batch 2 -> 1 sample per rank at world 2
+        tr.ddp_bucket_bytes = 2 << 20          # the 3-stage test network has 11 MB of gradients: several buckets
         tr.initialize()
         assert tr.is_ddp and tr.batch_size == 2 // world
         assert (tr.reducer is not None) and (tr.reducer.world == world)

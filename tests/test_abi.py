@@ -15,7 +15,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)  # strip comments
     decls = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char \*)\s*\*?\s*(mvd_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long|size_t|const char \*)\s*\*?\s*(mvd_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         decls[name] = n
@@ -28,7 +28,7 @@ def test_header_declares_the_whole_path():
                  "mvd_convT3d_wgrad", "mvd_instnorm_lrelu_fwd", "mvd_instnorm_lrelu_bwd", "mvd_seghead_fwd",
                  "mvd_seghead_bwd", "mvd_dcce_fwd", "mvd_dcce_bwd", "mvd_kl_fwd", "mvd_kl_bwd", "mvd_soft_erode_fwd",
                  "mvd_soft_dilate_fwd", "mvd_skel_update_fwd", "mvd_cc_label", "mvd_sgd_nesterov_step",
-                 "mvd_last_error", "mvd_version"):
+                 "mvd_h0_sorted_edges", "mvd_h0_pair_host", "mvd_mse_fwd", "mvd_last_error", "mvd_version"):
         assert must in d, must
 
 

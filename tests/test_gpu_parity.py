@@ -440,6 +440,66 @@ def test_cc_label_large_vs_c_oracle(conn):
         assert int(count.item()) == fill and int(labels.max().item()) == fill
 
 
+def test_h0_persistence_equals_reference_cpp_fixture():
+    """H0 birth/death pairing in the product (device edge keys + radix sort, host elder-rule sweep) against the diagrams
+    the reference's own C++ produced (hom.cpp / cohom.cpp compiled from /root/reference): equal as multisets."""
+    from multimodal_mvd_seg_amd import ops
+    d = json.load(open(os.path.join(GOLDEN, "persistence_grid.json")))
+    for case in d["cases"]:
+        f = np.asarray(case["f"], dtype=np.float32).reshape(case["shape"])
+        b, de, dv = ops.h0_persistence(G(f), case["conn"])
+        got = np.stack([b.numpy(), de.numpy()], 1)
+        got = got[np.lexsort((got[:, 1], got[:, 0]))]
+        want = np.array([[x, np.inf if y is None else y] for x, y in case["dgm0_sorted"]], dtype=np.float32)
+        assert np.array_equal(got, want), case["shape"]
+
+
+@pytest.mark.parametrize("conn", [6, 14, 26])
+@pytest.mark.parametrize("sublevel", [True, False])
+def test_h0_persistence_large_vs_c_oracle(conn, sublevel):
+    """bit-exact, bar for bar (same tie-breaking), incl. the critical vertices used for back-propagation; tie-heavy and
+    tie-free fields; the essential bars count the connected components"""
+    from multimodal_mvd_seg_amd import ops
+    from oracle import cc_oracle
+    rng = np.random.default_rng(17 + conn)
+    for shape, ties in (((40, 48, 36), False), ((24, 30, 28), True), ((1, 64, 80), True)):
+        f = rng.standard_normal(shape).astype(np.float32)
+        if ties:
+            f = np.round(f * 3) / 3
+        b, de, dv = ops.h0_persistence(G(f), conn, sublevel)
+        ob, ode, odv = cc_oracle.h0_persistence(f, conn, sublevel)
+        assert np.array_equal(b.numpy(), ob) and np.array_equal(de.numpy(), ode) and np.array_equal(dv.numpy(), odv)
+        assert int(torch.isinf(de).sum()) == 1
+
+
+def test_h0_diagram_backward_is_the_reference_scatter():
+    """persistence_backward (cohom.cpp:148-196): d birth -> the bar's own vertex, d death -> the critical vertex of the
+    killing edge, essential bars contribute their birth only"""
+    from multimodal_mvd_seg_amd import ops
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal((6, 7, 8)).astype(np.float32)
+    gf = G(f, True)
+    dgm = ops.H0DiagramFn.apply(gf, 6, True)
+    assert tuple(dgm.shape) == (f.size, 2) and not dgm.is_cuda
+    finite = torch.isfinite(dgm[:, 1])
+    w = torch.from_numpy(rng.standard_normal((f.size, 2)).astype(np.float32))
+    (torch.where(finite[:, None], dgm, torch.zeros(())) * w).sum().backward()
+    _, _, dv = ops.h0_persistence(G(f), 6, True)
+    want = torch.where(finite, w[:, 0], torch.zeros(())).clone()
+    want.index_add_(0, dv[finite], w[:, 1][finite])
+    # the essential bar's birth still receives its gradient when the loss uses it
+    assert torch.equal(gf.grad.cpu().reshape(-1), want)
+    # total persistence of the finite bars: d/df via the layer == analytic (+1 on death vertices, -1 on births)
+    gf2 = G(f, True)
+    dgm2 = ops.H0DiagramFn.apply(gf2, 6, True)
+    fin = torch.isfinite(dgm2[:, 1])
+    (dgm2[fin, 1] - dgm2[fin, 0]).sum().backward()
+    want2 = torch.zeros(f.size)
+    want2[fin] -= 1
+    want2.index_add_(0, dv[fin], torch.ones(int(fin.sum())))
+    assert torch.equal(gf2.grad.cpu().reshape(-1), want2)
+
+
 # ================================================================================================ optimizer
 def test_fused_sgd_matches_torch_sgd_with_clipping():
     from multimodal_mvd_seg_amd import optim
@@ -939,9 +999,9 @@ def test_packed_weight_cache_follows_every_kind_of_update():
         opt.step()                              # raw-pointer update + repack_all
         e = conv.weight._mvd_pack
         if query("mvd_wino_mode") != 1:  # F(2,3) tables are not in the batch entry: those entries go stale and are
-            assert e.stamp == ops._pack_stamp(conv.weight.detach())  # re-packed per layer by the next forward
+            assert e.stamp == ops._pack_stamp(conv.weight.detach(), conv.weight)  # re-packed per layer by the next forward
         y1, z1 = check("after optimizer step")
-        assert e.stamp == ops._pack_stamp(conv.weight.detach())
+        assert e.stamp == ops._pack_stamp(conv.weight.detach(), conv.weight)
         # the batched pack == the per-layer pack, bit for bit
         wf, wb = ops.pack_weight(conv.weight, False)
         assert torch.equal(wf, e.wf) and torch.equal(wb, e.wb)
