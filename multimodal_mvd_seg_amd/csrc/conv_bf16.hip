@@ -20,6 +20,23 @@ namespace mvd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Epilogue store widening (guide T21): after a swapped-operand 32x32 MFMA chain lane (i, h) holds, per channel group
+// rg, the packed bf16 x 4 of channels 8rg + 4h .. +3 of voxel i.  One v_permlane32_swap per dword turns the pair of
+// groups (k, k+1) into 16 contiguous bytes per lane: lanes 0-31 get channels 8k .. 8k+7, lanes 32-63 channels
+// 8k+8 .. 8k+15 -> one 16-byte store at byte offset 16k (+16 for the upper half) instead of two 8-byte ones.  The
+// 8-byte stores are issue-bound (~7 B/clk/CU), not bandwidth-bound.
+__device__ inline uint4 pair_store_image(uint2 a /* group k */, uint2 b /* group k+1 */) {
+    auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    return make_uint4(rx[0], ry[0], rx[1], ry[1]);
+}
+__device__ inline uint2 pack_bf16x4(float a, float b, float c, float d) {
+    uint2 q;
+    q.x = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+    q.y = (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16);
+    return q;
+}
+
 __host__ __device__ inline size_t widx16(int T, int K, int t, int c, int k) {
     const int cc = c >> 5, r = c & 31, s = r >> 4, h = (r >> 3) & 1, e = r & 7;
     return ((((((size_t)cc * T + t) * 2 + s) * 2 + h) * K + k) << 3) + e;
@@ -205,37 +222,51 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     // channels (r & 3) + 8 * (r >> 2) + 4 * h -- a lane holds 4 x 4 consecutive channels of ONE voxel and stores them as
     // 8-byte bf16 packets (sixteen 2-byte stores per tile cost more than the tile's MFMAs)
     const int od = od0 + wave;
-    if (od >= g.Do) return;
+    if (od >= g.Do) return;  // wave-uniform
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         const int oh = oh0 + 4 * m + (i >> 3), ow = ow0 + (i & 7);
-        if (oh >= g.Ho || ow >= g.Wo) continue;
+        const bool inside = oh < g.Ho && ow < g.Wo;  // (every lane takes part in the lane-half exchange below)
         const size_t o_lin = ((size_t)od * g.Ho + oh) * g.Wo + ow;
         const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
                           (ow * g.so[2] + g.oo[2]);
 #pragma unroll
-        for (int q = 0; q < NT; q++)
+        for (int q = 0; q < NT; q++) {
+            if (tg.S > 1) {
 #pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                const int k = kb * KT + q * 32 + 8 * rg + 4 * h;
-                if (tg.S > 1) {
-                    *reinterpret_cast<float4 *>(part + (((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k) =
-                        make_float4(acc[m][q][rg * 4 + 0], acc[m][q][rg * 4 + 1], acc[m][q][rg * 4 + 2], acc[m][q][rg * 4 + 3]);
-                } else {
-                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (bias) {
-                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + k);
-                        bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+                for (int rg = 0; rg < 4; rg++) {
+                    const int k = kb * KT + q * 32 + 8 * rg + 4 * h;
+                    if (inside)
+                        *reinterpret_cast<float4 *>(part + (((size_t)split * g.N + n) * ((size_t)g.Do * g.Ho * g.Wo) + o_lin) * tg.K + k) =
+                            make_float4(acc[m][q][rg * 4 + 0], acc[m][q][rg * 4 + 1], acc[m][q][rg * 4 + 2], acc[m][q][rg * 4 + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int kp = 0; kp < 2; kp++) {  // channel groups 2kp, 2kp+1: one 16-byte store per lane (T21)
+                    uint2 pk[2];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int rg = 2 * kp + e;
+                        const int k = kb * KT + q * 32 + 8 * rg + 4 * h;
+                        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (bias) {
+                            const float4 b4 = *reinterpret_cast<const float4 *>(bias + k);
+                            bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+                        }
+                        pk[e] = pack_bf16x4(acc[m][q][rg * 4 + 0] + bv[0], acc[m][q][rg * 4 + 1] + bv[1],
+                                            acc[m][q][rg * 4 + 2] + bv[2], acc[m][q][rg * 4 + 3] + bv[3]);
                     }
-                    uint2 pk;
-                    pk.x = (unsigned)f2bf(acc[m][q][rg * 4 + 0] + bv[0]) | ((unsigned)f2bf(acc[m][q][rg * 4 + 1] + bv[1]) << 16);
-                    pk.y = (unsigned)f2bf(acc[m][q][rg * 4 + 2] + bv[2]) | ((unsigned)f2bf(acc[m][q][rg * 4 + 3] + bv[3]) << 16);
-                    if (k < g.K1)
-                        *reinterpret_cast<uint2 *>(y1 + ov * g.K1 + k) = pk;
-                    else
-                        *reinterpret_cast<uint2 *>(y2 + ov * g.K2 + (k - g.K1)) = pk;
+                    const uint4 img = pair_store_image(pk[0], pk[1]);
+                    const int k = kb * KT + q * 32 + 16 * kp + 8 * h;  // first of this lane's 8 consecutive channels
+                    if (inside) {
+                        if (k < g.K1)
+                            *reinterpret_cast<uint4 *>(y1 + ov * g.K1 + k) = img;
+                        else
+                            *reinterpret_cast<uint4 *>(y2 + ov * g.K2 + (k - g.K1)) = img;
+                    }
                 }
             }
+        }
     }
 }
 
@@ -472,6 +503,238 @@ __global__ __launch_bounds__(512, 2) void k_fwd16p(const FwdGeom g, const Fwd16T
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ k_fwd16q (round 2)
+// Same shape class as k_fwd16p (3x3x3 stride 1, 32 -> 32 channels, >= 4 tiles per CU) with the two things its ablation
+// blamed removed: (1) the 3-way LDS bank conflicts of the A-operand reads -- halo slots are now the bare
+// 64-byte voxel rows and the four 16-byte parts of a row are XOR-swizzled with (halo y-row & 3): a ds_read_b128 lane
+// group covers 4 x-runs of 4 consecutive voxels in 4 consecutive y-rows, so x & 3 picks the bank quad inside a row group
+// and the swizzle separates the rows -- conflict-free for every tap (tools: brute force over layouts, round 2);
+// (2) the B-operand traffic: LDS carried two reads per MFMA (A and B), i.e. it was the bound even conflict-free.  Now a
+// workgroup is 4 waves (one per SIMD, 512 registers each) and every lane keeps ALL 27 taps' B fragments (its 54 16-byte
+// weight fragments, 216 VGPRs) for the whole walk; a wave owns one z-plane of the 4x8x8 tile = two 32-voxel M tiles that
+// share each B fragment: one LDS read per MFMA, issued a tap ahead; tap offsets are immediates.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// B fragments live in the ACCUMULATOR half of the register file for the whole walk (216 + 32 accumulator registers = 248
+// of 256 AGPRs) and the MFMA reads them there: with the builtin hipcc parks them in AGPRs anyway but copies each one to a
+// VGPR before use (179 v_accvgpr_read + 141 v_mov per tile, PMC: 672 VALU per 108 MFMAs).  `s_nop 1`: a VALU-written
+// A fragment (a compiler copy) needs two wait states before the MFMA reads it and nothing inside an asm string is
+// padded; accumulate chains on the same registers need none (guide 5.7 item 2).
+#define MVD_MFMA16_AB(ACC, BFRAG, AFRAG) \
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(BFRAG), "v"(AFRAG))
+#define MVD_MFMA16_AB_NONOP(ACC, BFRAG, AFRAG) \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "a"(BFRAG), "v"(AFRAG))
+constexpr int Q_TPB = 256;
+constexpr int Q_XR = 10;                 // uint4 per thread: 600 slots x 4 parts / 256
+constexpr int Q_HALO = 600 * 64;
+
+struct Fwd16QTile {
+    int ntd, nth, ntw, nitems;
+    int wsel[27];  // weight tap index of the raster tap (dz, dy, dx) = offsets -1..1
+};
+
+// DBG (compile time; 0 in production): ablation switches for tools/bench_conv.py -- 1 no halo traffic after the first
+// tile, 2 no MFMAs, 4 no output stores (results are then wrong by construction)
+//
+// One wave per SIMD has nobody to hide behind, so everything else is threaded through the 108-MFMA stream of a tile by
+// hand and kept cheap in VALU terms (PMC, round 2: the first version spent 613 VALU instructions per tile and wave on
+// address arithmetic, clamps and selects -- more than the ~540 issue slots the MFMAs leave free):
+//   * halo loads of the NEXT tile at the head of the tile; interior tiles (72 % at 128^3) use scalar-base + precomputed
+//     32-bit lane offsets, no bounds arithmetic at all; border tiles clamp the coordinates and zero on the way to LDS;
+//   * its ten LDS writes one per tap behind taps 14..23 into the other halo buffer, a barrier behind tap 24 (counted
+//     lgkmcnt: the A reads in flight are not drained), and the first two fragment groups of the next tile are already
+//     fetched under taps 25/26 -- no LDS fill bubble at the tile boundary;
+//   * the accumulators start from the bias and move to VGPRs when the tile is done; the conversion to bf16 and the
+//     eight 8-byte stores go between the first taps of the next tile.
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void k_fwd16q(const FwdGeom g, const Fwd16QTile tg, const unsigned short *__restrict__ a1,
+                                                   const unsigned short *__restrict__ w, const float *__restrict__ bias,
+                                                   unsigned short *__restrict__ y1) {
+    constexpr int dbg = DBG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3;
+
+    // resident B fragments: raster tap p, k-step s -> 16 bytes of lane (i, h)
+    i32x4 bw[27][2];
+#pragma unroll
+    for (int p = 0; p < 27; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(w + ((size_t)tg.wsel[p] * 128 + (s2 * 2 + h) * 32 + i) * 8);
+            bw[p][s2] = *reinterpret_cast<const i32x4 *>(&q);
+        }
+    // staging slots of this thread (tile independent): byte offset from the tile's first halo voxel, LDS byte offset
+    unsigned rel[Q_XR];
+    int wa[Q_XR];
+#pragma unroll
+    for (int u = 0; u < Q_XR; u++) {
+        const int idx = u * Q_TPB + tid;
+        const int slot = idx < 2400 ? (idx >> 2) : 599;  // slots >= 600 (last pass, tid >= 96) are loaded, never stored
+        const int ez = slot / 100, rem = slot - ez * 100;
+        const int ey = rem / 10, ex = rem - ey * 10;
+        rel[u] = (unsigned)(((ez * g.Hi + ey) * g.Wi + ex) * 64 + (idx & 3) * 16);
+        wa[u] = slot * 64 + (((idx & 3) ^ (ey & 3)) << 4);
+    }
+    // A-operand read addresses: M tile m (rows 4m..4m+3), halo row shift dy, k-step s (the tap offset is an immediate)
+    int ra[2][3][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int yl = 4 * m + (i >> 3);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+                ra[m][dy][s2] = ((wave * 10 + yl) * 10 + (i & 7)) * 64 + ((((s2 << 1) | h) ^ ((yl + dy) & 3)) << 4);
+    }
+    // the bias in accumulator layout (register r <-> output channel (r & 3) + 8 * (r >> 2) + 4 * h): C operand of tap 0
+    f32x16 biasv;
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b4 = *reinterpret_cast<const float4 *>(bias + 8 * rg + 4 * h);
+        biasv[rg * 4 + 0] = b4.x; biasv[rg * 4 + 1] = b4.y; biasv[rg * 4 + 2] = b4.z; biasv[rg * 4 + 3] = b4.w;
+    }
+    uint4 v[Q_XR];
+    int n_, od0, oh0, ow0;
+    unsigned inb = ~0u;  // bit u: slot u of this thread lies inside the volume (border tiles only)
+    auto decode = [&](int it) {
+        unsigned r_ = (unsigned)(xcd * per_xcd + it);
+        ow0 = (int)(r_ % (unsigned)tg.ntw) * 8; r_ /= (unsigned)tg.ntw;
+        oh0 = (int)(r_ % (unsigned)tg.nth) * 8; r_ /= (unsigned)tg.nth;
+        od0 = (int)(r_ % (unsigned)tg.ntd) * 4;
+        n_ = (int)(r_ / (unsigned)tg.ntd);
+    };
+    auto valid = [&](int it) { return it < per_xcd && xcd * per_xcd + it < tg.nitems; };
+    auto load_halo = [&]() {
+        const int z0 = od0 - 1, y0 = oh0 - 1, x0 = ow0 - 1;
+        const bool interior = z0 >= 0 && z0 + 6 <= g.Di && y0 >= 0 && y0 + 10 <= g.Hi && x0 >= 0 && x0 + 10 <= g.Wi;
+        if (interior) {  // block-uniform: scalar base + per-lane constant offset
+            const char *tb = reinterpret_cast<const char *>(a1) + ((((long)n_ * g.Di + z0) * g.Hi + y0) * g.Wi + x0) * 64L;
+            inb = ~0u;
+#pragma unroll
+            for (int u = 0; u < Q_XR; u++) v[u] = *reinterpret_cast<const uint4 *>(tb + rel[u]);
+        } else {
+            const unsigned short *base = a1 + (long)n_ * g.Di * g.Hi * g.Wi * 32L + (tid & 3) * 8;
+            inb = 0;
+#pragma unroll
+            for (int u = 0; u < Q_XR; u++) {
+                const int idx = u * Q_TPB + tid;
+                const int slot = idx < 2400 ? (idx >> 2) : 599;
+                const int ez = slot / 100, rem = slot - ez * 100;
+                const int ey = rem / 10, ex = rem - ey * 10;
+                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
+                const bool in = id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+                inb |= in ? (1u << u) : 0u;
+                const int cd = min(max(id, 0), g.Di - 1), ch = min(max(ih, 0), g.Hi - 1), cw = min(max(iw, 0), g.Wi - 1);
+                v[u] = *reinterpret_cast<const uint4 *>(base + ((cd * g.Hi + ch) * g.Wi + cw) * 32);
+            }
+        }
+    };
+    auto store_halo_piece = [&](unsigned char *Xs, int u) {
+        const bool in = (inb >> u) & 1u;
+        uint4 q;
+        q.x = in ? v[u].x : 0u; q.y = in ? v[u].y : 0u; q.z = in ? v[u].z : 0u; q.w = in ? v[u].w : 0u;
+        if (u < Q_XR - 1 || tid < 96) *reinterpret_cast<uint4 *>(Xs + wa[u]) = q;  // 600 slots: the last pass is partial
+    };
+
+    int it = local;
+    if (!valid(it)) return;  // whole workgroup
+    decode(it);
+    load_halo();
+#pragma unroll
+    for (int u = 0; u < Q_XR; u++) store_halo_piece(lds8, u);
+    // the weight fragments are consumed by asm statements only: make their loads complete HERE, once -- otherwise the
+    // wait for them lands at the loop head as `s_waitcnt vmcnt(0)` and drains the output stores every tile
+#pragma unroll
+    for (int p = 0; p < 27; p++) asm volatile("" : "+a"(bw[p][0]), "+a"(bw[p][1]));
+    __syncthreads();
+    int cur = 0;
+    float pe[2][16];
+    unsigned short *pyo[2] = {nullptr, nullptr};  // output address of this lane's voxel in M tile m (nullptr: outside)
+    bool have_prev = false;
+    auto epilogue_piece = [&](int m, int kp) {  // channel groups 2kp, 2kp+1 of M tile m: one 16-byte store per lane
+        const int k = 2 * kp;
+        const uint4 q = pair_store_image(
+            pack_bf16x4(pe[m][k * 4 + 0], pe[m][k * 4 + 1], pe[m][k * 4 + 2], pe[m][k * 4 + 3]),
+            pack_bf16x4(pe[m][k * 4 + 4], pe[m][k * 4 + 5], pe[m][k * 4 + 6], pe[m][k * 4 + 7]));
+        if (pyo[m] && !(dbg & 4)) *reinterpret_cast<uint4 *>(pyo[m] + 8 * k) = q;
+    };
+    i32x4 af[3][2][2];  // ring of 3 tap groups x [m][k-step]: fragments are fetched TWO taps (8 MFMAs) ahead, across tiles
+    auto read_a = [&](const unsigned char *Xs, int p, int buf) {
+        const int dz = p / 9, dy = (p / 3) % 3, dx = p % 3;
+        const int to = ((dz * 10 + dy) * 10 + dx) * 64;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(Xs + ra[m][dy][s2] + to);
+                af[buf][m][s2] = *reinterpret_cast<const i32x4 *>(&q);
+            }
+    };
+    read_a(lds8, 0, 0);
+    read_a(lds8, 1, 1);
+    while (true) {
+        const int itn = it + nlocal;
+        const bool more = valid(itn);  // block-uniform
+        const int cn = n_, cod0 = od0, coh0 = oh0, cow0 = ow0;
+        if (more) {
+            decode(itn);
+            if (!(dbg & 1)) load_halo();  // in flight during this tile's MFMAs
+        }
+        const unsigned char *Xs = lds8 + (size_t)cur * Q_HALO;
+        unsigned char *Xn = lds8 + (size_t)(cur ^ 1) * Q_HALO;
+        f32x16 acc[2] = {biasv, biasv};  // (C and D of an MFMA share one register file: the bias cannot be a VGPR C operand)
+#pragma unroll
+        for (int p = 0; p < 27; p++) {
+            if (p + 2 < 27) read_a(Xs, p + 2, (p + 2) % 3);
+            else if (more && !(dbg & 8)) read_a(Xn, p + 2 - 27, (p + 2) % 3);  // next tile's taps 0, 1 (behind the barrier of tap 24)
+            if ((p == 1 || p == 3 || p == 5 || p == 7) && have_prev) epilogue_piece((p - 1) >> 2, ((p - 1) >> 1) & 1);
+            if (!(dbg & 8) && p >= 14 && p <= 23 && more && !(dbg & 1)) store_halo_piece(Xn, p - 14);
+            if ((dbg & 8) && p >= 17 && p <= 26 && more && !(dbg & 1)) store_halo_piece(Xn, p - 17);
+            if (!(dbg & 8) && p == 24 && more) {
+                // every wave's halo writes (the newest: tap 23, four LDS reads ago) done and visible; the A reads in
+                // flight stay in flight
+                asm volatile("s_waitcnt lgkmcnt(4)\n\ts_barrier" ::: "memory");
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int m = 0; m < 2; m++)
+                    // operands swapped (D^T = W^T X^T): a lane ends with 4 x 4 consecutive output channels of one voxel
+                    if (!(dbg & 2)) MVD_MFMA16_AB(acc[m], bw[p][s2], af[p % 3][m][s2]);
+        }
+        // an MFMA result needs 12 wait states before anything but an accumulating MFMA touches it
+        asm volatile("s_nop 7\n\ts_nop 4" : "+a"(acc[0]), "+a"(acc[1]));
+        {
+            const int od = cod0 + wave;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) pe[m][r] = acc[m][r];
+                const int oh = coh0 + 4 * m + (i >> 3), ow = cow0 + (i & 7);
+                pyo[m] = (od < g.Do && oh < g.Ho && ow < g.Wo)
+                             ? y1 + ((((size_t)cn * g.Dy + od) * g.Hy + oh) * g.Wy + ow) * 32 + 8 * h
+                             : nullptr;
+            }
+            have_prev = true;
+        }
+        if (!more) break;
+        if (dbg & 8) {  // experiment: staging at the very end of the tile, plain barrier, LDS fill bubble
+            __syncthreads();
+            read_a(Xn, 0, 0);
+            read_a(Xn, 1, 1);
+        }
+        cur ^= 1;
+        it = itn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) epilogue_piece(j >> 1, j & 1);  // the last tile
+}
+
 static int num_cus16() {
     static int n = 0;
     if (!n) {
@@ -513,6 +776,40 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
     if (nitems < 4 * ncu || nitems > (1L << 30)) return -1;  // a walk of >= 4 tiles per workgroup or it does not pay
     if ((long)g.N * g.Di * g.Hi * g.Wi * 32 >= (1L << 31)) return -1;  // 32-bit element offsets inside a tile
     tg.nitems = (int)nitems;
+    static const int use_q = getenv("MVD_FWD16Q") ? atoi(getenv("MVD_FWD16Q")) : 1;
+    if (use_q) {
+        Fwd16QTile tq;
+        memset(&tq, 0, sizeof(tq));
+        tq.ntd = tg.ntd; tq.nth = tg.nth; tq.ntw = tg.ntw; tq.nitems = tg.nitems;
+        bool ok = true;
+        for (int p = 0; p < 27 && ok; p++) {
+            const int dz = p / 9 - 1, dy = (p / 3) % 3 - 1, dx = p % 3 - 1;
+            int hit = -1;
+            for (int t = 0; t < 27; t++)
+                if (g.off[t][0] == dz && g.off[t][1] == dy && g.off[t][2] == dx) hit = t;
+            if (hit < 0) ok = false;
+            else tq.wsel[p] = g.wt[hit];
+        }
+        if (ok) {
+            static const int dbgq = getenv("MVD_FWD16Q_DBG") ? atoi(getenv("MVD_FWD16Q_DBG")) & 15 : 0;
+            typedef void (*kq_t)(const FwdGeom, const Fwd16QTile, const unsigned short *, const unsigned short *, const float *,
+                                 unsigned short *);
+            static const kq_t kq[16] = {k_fwd16q<0>, k_fwd16q<1>, k_fwd16q<2>, k_fwd16q<3>, k_fwd16q<4>, k_fwd16q<5>,
+                                        k_fwd16q<6>, k_fwd16q<7>, k_fwd16q<8>, k_fwd16q<9>, k_fwd16q<10>, k_fwd16q<11>,
+                                        k_fwd16q<12>, k_fwd16q<13>, k_fwd16q<14>, k_fwd16q<15>};
+            static bool configured_q = false;
+            if (!configured_q) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq[dbgq]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_LIMIT16) != hipSuccess) {
+                    set_error("conv fwd16q: cannot raise the dynamic LDS limit");
+                    return 1;
+                }
+                configured_q = true;
+            }
+            hipLaunchKernelGGL(kq[dbgq], dim3((unsigned)ncu), dim3(Q_TPB), 2 * (size_t)Q_HALO, s, g, tq, a1, w, bias, y1);
+            return check_launch("conv fwd16q (persistent bf16 mfma, weights in registers)");
+        }
+    }
     const size_t lds = (size_t)P_WB + 2 * (size_t)P_HALO;
     static bool configured = false;
     if (!configured) {
