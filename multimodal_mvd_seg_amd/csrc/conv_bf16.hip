@@ -65,10 +65,14 @@ struct Fwd16Tile {
     int nitems;
     int K;
     int toff[27];
+    signed char tdy[28];  // halo row shift of tap t (off[t][1] - min_off[1]): selects the XOR swizzle of the read
 };
 
 // XR: uint4 (8 bf16) per thread of the halo tile = ceil(nslots*4/256)
-template <int NT, int MT, int TG, int XR>
+// SWZ (unit gather stride in every axis): halo slots are the bare 64-byte voxel rows with the four 16-byte parts XOR-swizzled
+// by (halo y-row & 3) -- conflict-free ds_read_b128 for every tap (see k_fwd16q); the padded 80-byte slots of the
+// strided layers are 3-way conflicted on unit-stride problems (PMC round 2: as many conflict cycles as access cycles).
+template <int NT, int MT, int TG, int XR, bool SWZ>
 __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
                                                   const unsigned short *__restrict__ a2,
                                                   const unsigned short *__restrict__ w, const float *__restrict__ bias,
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                                                   float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     constexpr int KT = 32 * NT;
-    constexpr int XS = 80;                       // bytes per halo slot (64 + 16 pad)
+    constexpr int XS = SWZ ? 64 : 80;            // bytes per halo slot (64 + 16 pad when not swizzled)
     constexpr int WROW = 16;                     // bytes per (tap, s, h, k) weight fragment
     constexpr int WR = TG * 4 * KT / 256;        // uint4 per thread per weight group (TG*2*2*KT fragments)
     constexpr int WBUF = TG * 4 * KT * WROW;     // bytes per weight buffer
@@ -109,7 +113,9 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     int sbase[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++)
-        sbase[m] = (((wave * g.sa[0]) * tg.EH + (4 * m + (i >> 3)) * g.sa[1]) * tg.EW + (i & 7) * g.sa[2]) * XS + h * 16;
+        sbase[m] = (((wave * g.sa[0]) * tg.EH + (4 * m + (i >> 3)) * g.sa[1]) * tg.EW + (i & 7) * g.sa[2]) * XS +
+                   (SWZ ? 0 : h * 16);
+    const int ylq = (i >> 3) & 3;  // (row of this lane inside its M tile) & 3; M tiles start at multiples of 4 rows
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; m++)
@@ -177,7 +183,13 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
 #pragma unroll
             for (int u = 0; u < XR; u++) {
                 const int idx = u * 256 + tid;
-                *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * XS + (idx & 3) * 16) = v[u];
+                int part = idx & 3;
+                if (SWZ) {
+                    const int slot = idx >> 2;
+                    const int ez = (slot * tg.magHW) >> 20, rem = slot - ez * EHW;
+                    part ^= ((rem * tg.magW) >> 20) & 3;  // halo y-row of the slot
+                }
+                *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * XS + part * 16) = v[u];
             }
         }
         for (int gi = 0; gi < ngroups; gi++) {
@@ -193,9 +205,10 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                 const int tl = j >> 1, s = j & 1;
                 const int t = gi * TG + tl < g.ntaps ? gi * TG + tl : g.ntaps - 1;  // block-uniform clamp
                 const int to = tg.toff[t] * XS;
+                const int xo = SWZ ? ((((s << 1) | h) ^ ((ylq + tg.tdy[t]) & 3)) << 4) : s * 32;
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    uint4 q = *reinterpret_cast<const uint4 *>(Xs + sbase[m] + to + s * 32);
+                    uint4 q = *reinterpret_cast<const uint4 *>(Xs + sbase[m] + to + xo);
                     af[buf][m] = *reinterpret_cast<bf16x8 *>(&q);
                 }
 #pragma unroll
@@ -297,12 +310,12 @@ __global__ void k_split_reduce16(const FwdGeom g, const float *__restrict__ part
 
 static const size_t LDS_LIMIT16 = 160 * 1024;
 
-template <int NT, int MT, int TG, int XR>
+template <int NT, int MT, int TG, int XR, bool SWZ>
 static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a1, const unsigned short *a2,
                         const unsigned short *w, const float *bias, unsigned short *y1, unsigned short *y2, void *ws,
                         size_t ws_bytes, hipStream_t s) {
-    auto kern = k_fwd16<NT, MT, TG, XR>;
-    const size_t lds = (size_t)XR * 64 * 80 + 2 * (size_t)TG * 4 * (32 * NT) * 16;
+    auto kern = k_fwd16<NT, MT, TG, XR, SWZ>;
+    const size_t lds = (size_t)XR * 64 * (SWZ ? 64 : 80) + 2 * (size_t)TG * 4 * (32 * NT) * 16;
     if (lds > LDS_LIMIT16) return -1;
     static bool configured = false;
     if (!configured) {
@@ -878,17 +891,24 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
         tg.nth = (g.Ho + 4 * MT - 1) / (4 * MT);
         tg.ntw = (g.Wo + 7) / 8;
         tg.K = K;
+        for (int t = 0; t < g.ntaps; t++) tg.tdy[t] = (signed char)(g.off[t][1] - mn[1]);
+        // measured (round 2, tools/bench_conv.py --dtype bf16): conflict-free reads do NOT pay in this kernel -- with two
+        // workgroups per CU it is bound by instruction issue, and the per-read swizzle arithmetic costs 12-15 %
+        // (64->64 @64^3: 0.151 -> 0.174 ms).  Kept selectable (MVD_FWD16_SWZ=1) as the measured alternative.
+        static const int swz_on = getenv("MVD_FWD16_SWZ") ? atoi(getenv("MVD_FWD16_SWZ")) : 0;
+        const bool swz = swz_on && g.sa[0] == 1 && g.sa[1] == 1 && g.sa[2] == 1;
         int r = -1;
+#define MVD_L16(NT_, MT_, TG_, XR_)                                                                              \
+    (swz ? launch_fwd16<NT_, MT_, TG_, XR_, true>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)             \
+         : launch_fwd16<NT_, MT_, TG_, XR_, false>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s))
         if (MT == 2) {
-            r = NT == 2 ? launch_fwd16<2, 2, 3, 10>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)
-                        : launch_fwd16<1, 2, 4, 10>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            r = NT == 2 ? MVD_L16(2, 2, 3, 10) : MVD_L16(1, 2, 4, 10);
         } else if (XR == 6) {
-            r = NT == 2 ? launch_fwd16<2, 1, 3, 6>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)
-                        : launch_fwd16<1, 1, 4, 6>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            r = NT == 2 ? MVD_L16(2, 1, 3, 6) : MVD_L16(1, 1, 4, 6);
         } else {
-            r = NT == 2 ? launch_fwd16<2, 1, 3, 22>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)
-                        : launch_fwd16<1, 1, 4, 22>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            r = NT == 2 ? MVD_L16(2, 1, 3, 22) : MVD_L16(1, 1, 4, 22);
         }
+#undef MVD_L16
         if (r >= 0) return r;
     }
     return -1;
