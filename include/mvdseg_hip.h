@@ -262,6 +262,15 @@ int mvd_skel_update_fwd(const float *img, const float *opened, const float *skel
 /* grads: d_img, d_opened (= -d_img masked), d_skel_in (NULL when init) from d_skel_out */
 int mvd_skel_update_bwd(const float *img, const float *opened, const float *skel_in, const float *d_skel_out,
                         float *d_img, float *d_opened, float *d_skel_in, long n, int init, void *stream);
+/* One whole soft_skel step (soft_skeleton.py:30-31 when init != 0, :33-36 otherwise) in one launch, LDS-tiled:
+ *   init:  o = dilate(erode(img));                     skel_out = relu(img - o)
+ *   else:  e1 = erode(img); o = dilate(erode(e1));     skel_out = skel_in + relu(d - skel_in * d), d = relu(e1 - o)
+ * Writes e1 (the next iteration's img; NULL when init), opened = o (saved for the backward of the update) and, when the
+ * pointers are non-NULL, the routing codes of the three stencils in the format of mvd_soft_erode_fwd /
+ * mvd_soft_dilate_fwd, so mvd_soft_erode_bwd / mvd_soft_dilate_bwd / mvd_skel_update_bwd back-propagate it.  Bit-exact
+ * with the primitive-per-launch chain. */
+int mvd_skel_iter_fwd(const float *img, const float *skel_in, float *e1, float *opened, float *skel_out, uint16_t *c_e1,
+                      uint16_t *c_e2, uint8_t *c_o, int NC, int D, int H, int W, int init, void *stream);
 /* sums for soft-clDice: out[0] = sum a*b, out[1] = sum a  (fixed-order) */
 int mvd_dot_sum(const float *a, const float *b, float *out, long n, void *ws, size_t ws_bytes, void *stream);
 size_t mvd_dot_sum_workspace_bytes(long n);

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mvd_soft_dilate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "mvd_skel_update_fwd": (c_int, [_P, _P, _P, _P, c_long, c_int, _P]),
     "mvd_skel_update_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_long, c_int, _P]),
+    "mvd_skel_iter_fwd": (c_int, [_P] * 8 + [c_int] * 5 + [_P]),
     "mvd_dot_sum": (c_int, [_P, _P, _P, c_long, _P, c_size_t, _P]),
     "mvd_dot_sum_workspace_bytes": (c_size_t, [c_long]),
     "mvd_cc_label": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -189,6 +189,142 @@ __global__ void k_skel_update_bwd(const float *__restrict__ img, const float *__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused skeleton iteration
+// One iteration of soft_skel (soft_skeleton.py:33-36) in ONE launch:
+//     e1 = erode(img);  e2 = erode(e1);  o = dilate(e2);  skel' = skel + relu(relu(e1 - o) - skel * relu(e1 - o))
+// (INIT: the step in front of the loop, :30-31: e1 := img, skel' = relu(img - o)).  The primitive-per-launch chain read and
+// wrote the 16.8 MB volume 11 times per iteration through four instruction-bound kernels (27 bounds-checked global
+// loads and three 64-bit divisions per voxel: k_dilate_fwd ran at 7 % of HBM); here a workgroup stages an 8x8x32 tile
+// with a halo of 3 in LDS once and walks the three stencils in LDS (halo 2 -> 1 -> 0).  Same arithmetic, same scan order
+// of the arg-min / arg-max, same routing codes: forward stays bit-exact and the existing backward kernels consume the
+// codes unchanged.  Volume borders: a neighbour outside the volume is skipped exactly as in the per-primitive kernels
+// (global coordinates, not tile coordinates, decide).
+constexpr int SK_TZ = 8, SK_TY = 8, SK_TX = 32;
+constexpr int SK_AZ = SK_TZ + 6, SK_AY = SK_TY + 6, SK_AX = SK_TX + 6;  // img, halo 3
+constexpr int SK_BZ = SK_TZ + 4, SK_BY = SK_TY + 4, SK_BX = SK_TX + 4;  // e1, halo 2
+constexpr int SK_CZ = SK_TZ + 2, SK_CY = SK_TY + 2, SK_CX = SK_TX + 2;  // e2, halo 1
+
+__device__ inline float erode_at(const float *p, int sz, int sy, int gz, int gy, int gx, int D, int H, int W, uint16_t &code) {
+    int a1, a2, a3;
+    const float p1 = axis_min(p, sz, gz, D, a1);
+    const float p2 = axis_min(p, sy, gy, H, a2);
+    const float p3 = axis_min(p, 1, gx, W, a3);
+    const float m12 = fminf(p1, p2);
+    const int c12 = p1 < p2 ? 0 : (p1 == p2 ? 1 : 2);
+    const int c3 = m12 < p3 ? 0 : (m12 == p3 ? 1 : 2);
+    code = (uint16_t)(a1 | (a2 << 2) | (a3 << 4) | (c12 << 6) | (c3 << 8));
+    return fminf(m12, p3);
+}
+
+template <bool INIT>
+__global__ __launch_bounds__(256) void k_skel_iter_fwd(const float *__restrict__ img, const float *__restrict__ skel_in,
+                                                       float *__restrict__ e1_out, float *__restrict__ opened_out,
+                                                       float *__restrict__ skel_out, uint16_t *__restrict__ c_e1,
+                                                       uint16_t *__restrict__ c_e2, uint8_t *__restrict__ c_o, int D, int H,
+                                                       int W, int ntz, int nty, int ntx) {
+    __shared__ float A[SK_AZ * SK_AY * SK_AX];
+    __shared__ float B[INIT ? 1 : SK_BZ * SK_BY * SK_BX];
+    __shared__ float Cc[SK_CZ * SK_CY * SK_CX];
+    const int tid = threadIdx.x;
+    unsigned b = blockIdx.x;
+    const int tx = (int)(b % (unsigned)ntx); b /= (unsigned)ntx;
+    const int ty = (int)(b % (unsigned)nty); b /= (unsigned)nty;
+    const int tz = (int)(b % (unsigned)ntz);
+    const long nc = (long)(b / (unsigned)ntz);
+    const int z0 = tz * SK_TZ, y0 = ty * SK_TY, x0 = tx * SK_TX;
+    const long HW = (long)H * W;
+    const float *src = img + nc * D * HW;
+    // stage A: the image with a halo of 3 (zeros outside the volume; they are never selected, see below)
+    for (int idx = tid; idx < SK_AZ * SK_AY * SK_AX; idx += 256) {
+        const int lx = idx % SK_AX, ly = (idx / SK_AX) % SK_AY, lz = idx / (SK_AX * SK_AY);
+        const int gz = z0 + lz - 3, gy = y0 + ly - 3, gx = x0 + lx - 3;
+        float v = 0.f;
+        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[(long)gz * HW + (long)gy * W + gx];
+        A[idx] = v;
+    }
+    __syncthreads();
+    // stage B: e1 = erode(img) on the tile + halo 2
+    if (!INIT) {
+        for (int idx = tid; idx < SK_BZ * SK_BY * SK_BX; idx += 256) {
+            const int lx = idx % SK_BX, ly = (idx / SK_BX) % SK_BY, lz = idx / (SK_BX * SK_BY);
+            const int gz = z0 + lz - 2, gy = y0 + ly - 2, gx = x0 + lx - 2;
+            float v = 0.f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                uint16_t code;
+                v = erode_at(A + ((lz + 1) * SK_AY + (ly + 1)) * SK_AX + (lx + 1), SK_AY * SK_AX, SK_AX, gz, gy, gx, D, H, W, code);
+                if (lz >= 2 && lz < 2 + SK_TZ && ly >= 2 && ly < 2 + SK_TY && lx >= 2 && lx < 2 + SK_TX) {
+                    const long o = nc * D * HW + (long)gz * HW + (long)gy * W + gx;
+                    e1_out[o] = v;
+                    if (c_e1) c_e1[o] = code;
+                }
+            }
+            B[idx] = v;
+        }
+        __syncthreads();
+    }
+    // stage C: e2 = erode(e1) on the tile + halo 1
+    for (int idx = tid; idx < SK_CZ * SK_CY * SK_CX; idx += 256) {
+        const int lx = idx % SK_CX, ly = (idx / SK_CX) % SK_CY, lz = idx / (SK_CX * SK_CY);
+        const int gz = z0 + lz - 1, gy = y0 + ly - 1, gx = x0 + lx - 1;
+        float v = 0.f;
+        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            uint16_t code;
+            if (INIT)
+                v = erode_at(A + ((lz + 2) * SK_AY + (ly + 2)) * SK_AX + (lx + 2), SK_AY * SK_AX, SK_AX, gz, gy, gx, D, H, W, code);
+            else
+                v = erode_at(B + ((lz + 1) * SK_BY + (ly + 1)) * SK_BX + (lx + 1), SK_BY * SK_BX, SK_BX, gz, gy, gx, D, H, W, code);
+            if (c_e2 && lz >= 1 && lz <= SK_TZ && ly >= 1 && ly <= SK_TY && lx >= 1 && lx <= SK_TX)
+                c_e2[nc * D * HW + (long)gz * HW + (long)gy * W + gx] = code;
+        }
+        Cc[idx] = v;
+    }
+    __syncthreads();
+    // stage D + E: o = dilate(e2), skeleton update, on the tile
+#pragma unroll
+    for (int u = 0; u < SK_TZ * SK_TY * SK_TX / 256; u++) {
+        const int j = u * 256 + tid;
+        const int lx = j % SK_TX, ly = (j / SK_TX) % SK_TY, lz = j / (SK_TX * SK_TY);
+        const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+        if (gz >= D || gy >= H || gx >= W) continue;
+        const float *q = Cc + ((lz + 1) * SK_CY + (ly + 1)) * SK_CX + (lx + 1);
+        float best = -INFINITY;
+        int arg = 13;
+        bool have = false;
+#pragma unroll
+        for (int a = -1; a <= 1; a++) {
+            if (gz + a < 0 || gz + a >= D) continue;
+#pragma unroll
+            for (int bb = -1; bb <= 1; bb++) {
+                if (gy + bb < 0 || gy + bb >= H) continue;
+#pragma unroll
+                for (int c = -1; c <= 1; c++) {
+                    if (gx + c < 0 || gx + c >= W) continue;
+                    const float v = q[(a * SK_CY + bb) * SK_CX + c];
+                    if (!have || v > best) {  // first maximum in scan order (max_pool3d)
+                        best = v;
+                        arg = (a + 1) * 9 + (bb + 1) * 3 + (c + 1);
+                        have = true;
+                    }
+                }
+            }
+        }
+        const long o = nc * D * HW + (long)gz * HW + (long)gy * W + gx;
+        opened_out[o] = best;
+        if (c_o) c_o[o] = (uint8_t)arg;
+        const float e1 = INIT ? A[((lz + 3) * SK_AY + (ly + 3)) * SK_AX + (lx + 3)]
+                              : B[((lz + 2) * SK_BY + (ly + 2)) * SK_BX + (lx + 2)];
+        const float delta = fmaxf(e1 - best, 0.f);
+        if (INIT) {
+            skel_out[o] = delta;
+        } else {
+            const float sk = skel_in[o];
+            const float prod = sk * delta;
+            skel_out[o] = sk + fmaxf(delta - prod, 0.f);
+        }
+    }
+}
+
+
 __global__ void k_dot_sum(const float *__restrict__ a, const float *__restrict__ b, double *__restrict__ partial,
                           long n) {
     __shared__ double red[2 * 16];
@@ -490,6 +626,24 @@ int mvd_skel_update_bwd(const float *img, const float *opened, const float *skel
     hipLaunchKernelGGL(k_skel_update_bwd, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), img, opened, skel_in,
                        d_skel_out, d_img, d_opened, d_skel_in, n, init);
     return check_launch("skel_update_bwd");
+}
+
+int mvd_skel_iter_fwd(const float *img, const float *skel_in, float *e1, float *opened, float *skel_out, uint16_t *c_e1,
+                      uint16_t *c_e2, uint8_t *c_o, int NC, int D, int H, int W, int init, void *stream) {
+    MVD_REQUIRE(img && opened && skel_out, "skel_iter_fwd: null pointer");
+    MVD_REQUIRE(init || (skel_in && e1), "skel_iter_fwd: an iteration needs skel_in and an e1 output");
+    VOL_CHECK("skel_iter_fwd");
+    const int ntz = (D + SK_TZ - 1) / SK_TZ, nty = (H + SK_TY - 1) / SK_TY, ntx = (W + SK_TX - 1) / SK_TX;
+    const long nb = (long)NC * ntz * nty * ntx;
+    MVD_REQUIRE(nb < (1L << 31), "skel_iter_fwd: volume too large");
+    hipStream_t s = as_stream(stream);
+    if (init)
+        hipLaunchKernelGGL(k_skel_iter_fwd<true>, dim3((unsigned)nb), dim3(256), 0, s, img, skel_in, e1, opened, skel_out, c_e1,
+                           c_e2, c_o, D, H, W, ntz, nty, ntx);
+    else
+        hipLaunchKernelGGL(k_skel_iter_fwd<false>, dim3((unsigned)nb), dim3(256), 0, s, img, skel_in, e1, opened, skel_out,
+                           c_e1, c_e2, c_o, D, H, W, ntz, nty, ntx);
+    return check_launch("skel_iter_fwd");
 }
 
 size_t mvd_dot_sum_workspace_bytes(long n) {

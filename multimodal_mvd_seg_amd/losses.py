@@ -122,7 +122,16 @@ def soft_open(img):
 
 
 def soft_skel(img, iter_):
-    """soft_skeleton.py:29-37."""
+    """soft_skeleton.py:29-37: one fused launch for the step in front of the loop and one per iteration
+    (erode -> erode -> dilate -> skeleton update walk an LDS tile; csrc/topo.hip::k_skel_iter_fwd)."""
+    skel = ops.SkelInitFn.apply(img)
+    for _ in range(iter_):
+        img, skel = ops.SkelIterFn.apply(img, skel)
+    return skel
+
+
+def soft_skel_unfused(img, iter_):
+    """The same chain one primitive per launch (the round-1 path; kept as the cross-check of the fused kernels)."""
     img1 = soft_open(img)
     skel = ops.SkelUpdateFn.apply(img, img1, None)
     for _ in range(iter_):

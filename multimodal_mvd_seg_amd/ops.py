@@ -897,6 +897,86 @@ class SkelUpdateFn(Function):
         return d_img, d_open, d_skel
 
 
+def _skel_iter(img, skel, want_codes):
+    """mvd_skel_iter_fwd on contiguous volumes; returns (e1 | None, opened, skel_out, c_e1 | None, c_e2, c_o)."""
+    NC, D, H, W = img.shape[0] * img.shape[1], *img.shape[2:]
+    init = skel is None
+    e1 = None if init else torch.empty_like(img)
+    opened, skel_out = torch.empty_like(img), torch.empty_like(img)
+    c_e1 = torch.empty(img.shape, dtype=torch.int16, device=img.device) if (want_codes and not init) else None
+    c_e2 = torch.empty(img.shape, dtype=torch.int16, device=img.device) if want_codes else None
+    c_o = torch.empty(img.shape, dtype=torch.uint8, device=img.device) if want_codes else None
+    call("mvd_skel_iter_fwd", _p(img), _p(skel), _p(e1), _p(opened), _p(skel_out), _p(c_e1), _p(c_e2), _p(c_o), NC, D, H, W,
+         int(init), _stream())
+    return e1, opened, skel_out, c_e1, c_e2, c_o
+
+
+def _skel_iter_bwd_tail(x, opened, skel, c_e2, c_o, g, dims, init):
+    """Shared backward of one fused step: (d e1 through the subtraction, d e1 through open(e1), d skel_in)."""
+    d_a, d_o = torch.empty_like(x), torch.empty_like(x)
+    d_skel = None if init else torch.empty_like(x)
+    call("mvd_skel_update_bwd", _p(x), _p(opened), _p(skel), _p(g), _p(d_a), _p(d_o), _p(d_skel), x.numel(), int(init),
+         _stream())
+    d_e2 = torch.empty_like(x)
+    call("mvd_soft_dilate_bwd", _p(c_o), _p(d_o), _p(d_e2), *dims, _stream())
+    d_b = torch.empty_like(x)
+    call("mvd_soft_erode_bwd", _p(c_e2), _p(d_e2), _p(d_b), *dims, _stream())
+    return d_a, d_b, d_skel
+
+
+class SkelInitFn(Function):
+    """skel0 = relu(img - open(img)) (soft_skeleton.py:30-31) in one LDS-tiled launch."""
+
+    @staticmethod
+    def forward(ctx, img):
+        _require_cuda(img)
+        img, NC, D, H, W = _vol(img)
+        need = ctx.needs_input_grad[0]
+        _, opened, skel0, _, c_e2, c_o = _skel_iter(img, None, need)
+        if need:
+            ctx.save_for_backward(img, opened, c_e2, c_o)
+        ctx.dims = (NC, D, H, W)
+        return skel0
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        img, opened, c_e2, c_o = ctx.saved_tensors
+        d_a, d_b, _ = _skel_iter_bwd_tail(img, opened, None, c_e2, c_o, g.contiguous(), ctx.dims, True)
+        return d_a.add_(d_b)  # autograd's order: the subtraction's share first, then the share through open()
+
+
+class SkelIterFn(Function):
+    """(img, skel) -> (erode(img), skel + relu(d - skel*d)), d = relu(erode(img) - open(erode(img))): one iteration of
+    the soft_skel loop (soft_skeleton.py:33-36) in one LDS-tiled launch."""
+
+    @staticmethod
+    def forward(ctx, img, skel):
+        _require_cuda(img, skel)
+        img, NC, D, H, W = _vol(img)
+        skel = skel.contiguous()
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        e1, opened, skel_out, c_e1, c_e2, c_o = _skel_iter(img, skel, need)
+        if need:
+            ctx.save_for_backward(e1, opened, skel, c_e1, c_e2, c_o)
+        ctx.dims = (NC, D, H, W)
+        return e1, skel_out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_e1, d_skel_out):
+        e1, opened, skel, c_e1, c_e2, c_o = ctx.saved_tensors
+        g = d_skel_out.contiguous() if d_skel_out is not None else torch.zeros_like(e1)
+        d_a, d_b, d_skel = _skel_iter_bwd_tail(e1, opened, skel, c_e2, c_o, g, ctx.dims, False)
+        # e1's consumers in creation order: open(e1), the subtraction, the next iteration's erode -> autograd adds their
+        # gradients in reverse: (next + subtraction) + open
+        total = d_a if d_e1 is None else d_e1.contiguous() + d_a
+        total = total.add_(d_b) if total is not d_a else d_a.add_(d_b)
+        d_img = torch.empty_like(e1)
+        call("mvd_soft_erode_bwd", _p(c_e1), _p(total), _p(d_img), *ctx.dims, _stream())
+        return d_img, d_skel
+
+
 class ClDiceFn(Function):
     """1 - 2*tprec*tsens/(tprec+tsens) from (skel_pred, target, skel_true, pred) (clDice_metric.py:7-36 formula)."""
 
