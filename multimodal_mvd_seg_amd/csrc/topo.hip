@@ -204,11 +204,20 @@ constexpr int SK_AZ = SK_TZ + 6, SK_AY = SK_TY + 6, SK_AX = SK_TX + 6;  // img, 
 constexpr int SK_BZ = SK_TZ + 4, SK_BY = SK_TY + 4, SK_BX = SK_TX + 4;  // e1, halo 2
 constexpr int SK_CZ = SK_TZ + 2, SK_CY = SK_TY + 2, SK_CX = SK_TX + 2;  // e2, halo 1
 
-__device__ inline float erode_at(const float *p, int sz, int sy, int gz, int gy, int gx, int D, int H, int W, uint16_t &code) {
+// min over a 3-window whose out-of-volume entries hold +inf (so they are never selected): first minimum in scan order
+__device__ inline float axis_min3(float lo, float mid, float hi, int &arg) {
+    float best = lo;
+    arg = 0;
+    if (mid < best) { best = mid; arg = 1; }
+    if (hi < best) { best = hi; arg = 2; }
+    return best;
+}
+__device__ inline float erode_padded(const float *p, int sz, int sy, uint16_t &code) {
     int a1, a2, a3;
-    const float p1 = axis_min(p, sz, gz, D, a1);
-    const float p2 = axis_min(p, sy, gy, H, a2);
-    const float p3 = axis_min(p, 1, gx, W, a3);
+    const float c = p[0];
+    const float p1 = axis_min3(p[-sz], c, p[sz], a1);
+    const float p2 = axis_min3(p[-sy], c, p[sy], a2);
+    const float p3 = axis_min3(p[-1], c, p[1], a3);
     const float m12 = fminf(p1, p2);
     const int c12 = p1 < p2 ? 0 : (p1 == p2 ? 1 : 2);
     const int c3 = m12 < p3 ? 0 : (m12 == p3 ? 1 : 2);
@@ -216,6 +225,11 @@ __device__ inline float erode_at(const float *p, int sz, int sy, int gz, int gy,
     return fminf(m12, p3);
 }
 
+// Out-of-volume cells of the LDS images hold +inf in the erode inputs (A, B) and -inf in the dilate input (C): a
+// neighbour outside the volume can then never be the (first) minimum / maximum, which is exactly what skipping it does
+// for finite data -- and the stencil loops carry no bounds logic (the first version, with per-neighbour coordinate
+// tests, was slower than the four separate launches it replaced).  Every stage pads its own output again (one
+// coordinate test per cell): +inf for e1, -inf for e2.
 template <bool INIT>
 __global__ __launch_bounds__(256) void k_skel_iter_fwd(const float *__restrict__ img, const float *__restrict__ skel_in,
                                                        float *__restrict__ e1_out, float *__restrict__ opened_out,
@@ -233,12 +247,13 @@ __global__ __launch_bounds__(256) void k_skel_iter_fwd(const float *__restrict__
     const long nc = (long)(b / (unsigned)ntz);
     const int z0 = tz * SK_TZ, y0 = ty * SK_TY, x0 = tx * SK_TX;
     const long HW = (long)H * W;
-    const float *src = img + nc * D * HW;
-    // stage A: the image with a halo of 3 (zeros outside the volume; they are never selected, see below)
+    const long vbase = nc * D * HW;
+    const float *src = img + vbase;
+    // stage A: the image with a halo of 3
     for (int idx = tid; idx < SK_AZ * SK_AY * SK_AX; idx += 256) {
         const int lx = idx % SK_AX, ly = (idx / SK_AX) % SK_AY, lz = idx / (SK_AX * SK_AY);
         const int gz = z0 + lz - 3, gy = y0 + ly - 3, gx = x0 + lx - 3;
-        float v = 0.f;
+        float v = INFINITY;
         if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[(long)gz * HW + (long)gy * W + gx];
         A[idx] = v;
     }
@@ -247,36 +262,33 @@ __global__ __launch_bounds__(256) void k_skel_iter_fwd(const float *__restrict__
     if (!INIT) {
         for (int idx = tid; idx < SK_BZ * SK_BY * SK_BX; idx += 256) {
             const int lx = idx % SK_BX, ly = (idx / SK_BX) % SK_BY, lz = idx / (SK_BX * SK_BY);
+            uint16_t code;
+            const float v = erode_padded(A + ((lz + 1) * SK_AY + (ly + 1)) * SK_AX + (lx + 1), SK_AY * SK_AX, SK_AX, code);
             const int gz = z0 + lz - 2, gy = y0 + ly - 2, gx = x0 + lx - 2;
-            float v = 0.f;
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                uint16_t code;
-                v = erode_at(A + ((lz + 1) * SK_AY + (ly + 1)) * SK_AX + (lx + 1), SK_AY * SK_AX, SK_AX, gz, gy, gx, D, H, W, code);
-                if (lz >= 2 && lz < 2 + SK_TZ && ly >= 2 && ly < 2 + SK_TY && lx >= 2 && lx < 2 + SK_TX) {
-                    const long o = nc * D * HW + (long)gz * HW + (long)gy * W + gx;
-                    e1_out[o] = v;
-                    if (c_e1) c_e1[o] = code;
-                }
+            const bool inside = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            B[idx] = inside ? v : INFINITY;  // (a cell just outside the volume has finite neighbours: pad it again)
+            if (inside && lz >= 2 && lz < 2 + SK_TZ && ly >= 2 && ly < 2 + SK_TY && lx >= 2 && lx < 2 + SK_TX) {
+                const long o = vbase + (long)gz * HW + (long)gy * W + gx;
+                e1_out[o] = v;
+                if (c_e1) c_e1[o] = code;
             }
-            B[idx] = v;
         }
         __syncthreads();
     }
-    // stage C: e2 = erode(e1) on the tile + halo 1
+    // stage C: e2 = erode(e1) on the tile + halo 1 (-inf outside the volume: it feeds the max)
     for (int idx = tid; idx < SK_CZ * SK_CY * SK_CX; idx += 256) {
         const int lx = idx % SK_CX, ly = (idx / SK_CX) % SK_CY, lz = idx / (SK_CX * SK_CY);
         const int gz = z0 + lz - 1, gy = y0 + ly - 1, gx = x0 + lx - 1;
-        float v = 0.f;
-        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            uint16_t code;
-            if (INIT)
-                v = erode_at(A + ((lz + 2) * SK_AY + (ly + 2)) * SK_AX + (lx + 2), SK_AY * SK_AX, SK_AX, gz, gy, gx, D, H, W, code);
-            else
-                v = erode_at(B + ((lz + 1) * SK_BY + (ly + 1)) * SK_BX + (lx + 1), SK_BY * SK_BX, SK_BX, gz, gy, gx, D, H, W, code);
-            if (c_e2 && lz >= 1 && lz <= SK_TZ && ly >= 1 && ly <= SK_TY && lx >= 1 && lx <= SK_TX)
-                c_e2[nc * D * HW + (long)gz * HW + (long)gy * W + gx] = code;
-        }
-        Cc[idx] = v;
+        uint16_t code;
+        float v;
+        if (INIT)
+            v = erode_padded(A + ((lz + 2) * SK_AY + (ly + 2)) * SK_AX + (lx + 2), SK_AY * SK_AX, SK_AX, code);
+        else
+            v = erode_padded(B + ((lz + 1) * SK_BY + (ly + 1)) * SK_BX + (lx + 1), SK_BY * SK_BX, SK_BX, code);
+        const bool inside = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        if (c_e2 && inside && lz >= 1 && lz <= SK_TZ && ly >= 1 && ly <= SK_TY && lx >= 1 && lx <= SK_TX)
+            c_e2[vbase + (long)gz * HW + (long)gy * W + gx] = code;
+        Cc[idx] = inside ? v : -INFINITY;
     }
     __syncthreads();
     // stage D + E: o = dilate(e2), skeleton update, on the tile
@@ -288,27 +300,20 @@ __global__ __launch_bounds__(256) void k_skel_iter_fwd(const float *__restrict__
         if (gz >= D || gy >= H || gx >= W) continue;
         const float *q = Cc + ((lz + 1) * SK_CY + (ly + 1)) * SK_CX + (lx + 1);
         float best = -INFINITY;
-        int arg = 13;
-        bool have = false;
+        int arg = 13;  // (a volume of one voxel: every neighbour is -inf and the centre wins below)
 #pragma unroll
-        for (int a = -1; a <= 1; a++) {
-            if (gz + a < 0 || gz + a >= D) continue;
+        for (int a = -1; a <= 1; a++)
 #pragma unroll
-            for (int bb = -1; bb <= 1; bb++) {
-                if (gy + bb < 0 || gy + bb >= H) continue;
+            for (int bb = -1; bb <= 1; bb++)
 #pragma unroll
                 for (int c = -1; c <= 1; c++) {
-                    if (gx + c < 0 || gx + c >= W) continue;
                     const float v = q[(a * SK_CY + bb) * SK_CX + c];
-                    if (!have || v > best) {  // first maximum in scan order (max_pool3d)
+                    if (v > best) {  // first maximum in scan order (max_pool3d)
                         best = v;
                         arg = (a + 1) * 9 + (bb + 1) * 3 + (c + 1);
-                        have = true;
                     }
                 }
-            }
-        }
-        const long o = nc * D * HW + (long)gz * HW + (long)gy * W + gx;
+        const long o = vbase + (long)gz * HW + (long)gy * W + gx;
         opened_out[o] = best;
         if (c_o) c_o[o] = (uint8_t)arg;
         const float e1 = INIT ? A[((lz + 3) * SK_AY + (ly + 3)) * SK_AX + (lx + 3)]
@@ -323,7 +328,6 @@ __global__ __launch_bounds__(256) void k_skel_iter_fwd(const float *__restrict__
         }
     }
 }
-
 
 __global__ void k_dot_sum(const float *__restrict__ a, const float *__restrict__ b, double *__restrict__ partial,
                           long n) {
