@@ -285,47 +285,25 @@ __global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restr
         long i = g0 + 4L * r;
         long n = i / V, v = i - n * V;
         const long step = 4L * R;
-        // software pipeline: the nine 16-byte loads of quad j+1 are in flight while quad j is accumulated (the loop was
-        // latency-bound: one dependent load -> FMA round per iteration, 1.1 TB/s at the 128^3 head)
-        float4 q[2][4], d[2][KMAX];
-        auto fetch = [&](int b, long ii, long nn, long vv) {
+        for (; i < g1; i += step) {
+            float4 q[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) q[b][u] = ld4<XB>(x, (size_t)(ii + u) * C + g * 4);
-#pragma unroll
-            for (int k = 0; k < KMAX; k++)
-                if (k < K) d[b][k] = *reinterpret_cast<const float4 *>(dl + ((size_t)nn * K + k) * V + vv);
-        };
-        auto accumulate = [&](int b) {
+            for (int u = 0; u < 4; u++) q[u] = ld4<XB>(x, (size_t)(i + u) * C + g * 4);
 #pragma unroll
             for (int k = 0; k < KMAX; k++)
                 if (k < K) {
-                    const float4 dd = d[b][k];
-                    acc[k][0] += dd.x * q[b][0].x + dd.y * q[b][1].x + dd.z * q[b][2].x + dd.w * q[b][3].x;
-                    acc[k][1] += dd.x * q[b][0].y + dd.y * q[b][1].y + dd.z * q[b][2].y + dd.w * q[b][3].y;
-                    acc[k][2] += dd.x * q[b][0].z + dd.y * q[b][1].z + dd.z * q[b][2].z + dd.w * q[b][3].z;
-                    acc[k][3] += dd.x * q[b][0].w + dd.y * q[b][1].w + dd.z * q[b][2].w + dd.w * q[b][3].w;
-                    accb[k] += (dd.x + dd.y) + (dd.z + dd.w);
+                    const float4 d = *reinterpret_cast<const float4 *>(dl + ((size_t)n * K + k) * V + v);
+                    acc[k][0] += d.x * q[0].x + d.y * q[1].x + d.z * q[2].x + d.w * q[3].x;
+                    acc[k][1] += d.x * q[0].y + d.y * q[1].y + d.z * q[2].y + d.w * q[3].y;
+                    acc[k][2] += d.x * q[0].z + d.y * q[1].z + d.z * q[2].z + d.w * q[3].z;
+                    acc[k][3] += d.x * q[0].w + d.y * q[1].w + d.z * q[2].w + d.w * q[3].w;
+                    accb[k] += (d.x + d.y) + (d.z + d.w);
                 }
-        };
-        if (i < g1) fetch(0, i, n, v);
-        // two quads per trip so that the buffer index is a compile-time constant (no register-array indexing)
-        while (i < g1) {
-            long i2 = i + step, n2 = n, v2 = v + step;
-            while (v2 >= V) {
-                v2 -= V;
-                n2++;
+            v += step;
+            while (v >= V) {
+                v -= V;
+                n++;
             }
-            if (i2 < g1) fetch(1, i2, n2, v2);
-            accumulate(0);
-            if (i2 >= g1) break;
-            long i3 = i2 + step, n3 = n2, v3 = v2 + step;
-            while (v3 >= V) {
-                v3 -= V;
-                n3++;
-            }
-            if (i3 < g1) fetch(0, i3, n3, v3);
-            accumulate(1);
-            i = i3; n = n3; v = v3;
         }
         float *o = smf + (size_t)r * nv_out;
 #pragma unroll
@@ -805,9 +783,11 @@ int mvd_seghead_fwd_bf16(const uint16_t *x, const float *w, const float *bias, f
 }
 
 static long seghead_chunk(long total, int *nblk) {
-    long nb = total / 2048;
+    // (a software-pipelined loop -- next quad's loads under this quad's FMAs -- was tried in round 2 and ran 1.4-2x
+    // SLOWER: 96 more registers per thread; what the pass lacked on the lower levels was workgroups, not overlap)
+    long nb = total / 512;
     if (nb < 1) nb = 1;
-    if (nb > 4096) nb = 4096;  // 16 workgroups per CU: the weight-gradient pass is a pure stream over x and dl
+    if (nb > 8192) nb = 8192;  // up to 32 workgroups per CU: the weight-gradient pass is a pure stream over x and dl
     long chunk = cdiv(total, nb);
     chunk = cdiv(chunk, 64) * 64;
     *nblk = (int)cdiv(total, chunk);
