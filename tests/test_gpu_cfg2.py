@@ -161,6 +161,42 @@ def test_cfg2_conv_exact_integer_data(name):
     assert torch.equal(gb.grad.cpu(), br.grad), f"{name}: db"
 
 
+@pytest.mark.parametrize("name", [n for n in CONVS if CONVS[n][0] % 32 == 0])
+def test_cfg2_conv_bf16_exact_integer_data(name):
+    """The bf16 engines (configs[3], [4]) at the real cfg-2 layer shapes, batch 2, on small-integer data: the operands are
+    exact in bf16, every product and fp32 partial sum is an exact integer, so y / dX must equal torch's exact fp32 result
+    rounded once to bf16 (round-to-nearest-even), and the fp32 weight / bias gradients must be exact -- bit for bit.
+    Covers k_fwd16q (32 -> 32 at 128^3), k_fwd16 in all its tile variants incl. the split-reduce path, k_wgrad16."""
+    from multimodal_mvd_seg_amd import ops
+    C1, C2, K, sp, st = CONVS[name]
+    g = torch.Generator().manual_seed(sum(name.encode()) + 1)
+    N = 2
+    x1 = _ints(g, (N, C1, sp, sp, sp), -2, 2)
+    x2 = _ints(g, (N, C2, sp, sp, sp), -2, 2) if C2 else None
+    w = _ints(g, (K, C1 + C2, 3, 3, 3), -2, 2)
+    b = _ints(g, (K,), -3, 3)
+    xs = [t.clone().requires_grad_() for t in ([x1, x2] if C2 else [x1])]
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.conv3d(torch.cat(xs, 1) if C2 else xs[0], wr, br, st, 1)
+    gy = _ints(g, tuple(ref.shape), -1, 1)
+    ref.backward(gy)
+    cl = torch.channels_last_3d
+    BF = torch.bfloat16
+    g1 = x1.to(DEV).to(BF).contiguous(memory_format=cl).requires_grad_()
+    g2 = x2.to(DEV).to(BF).contiguous(memory_format=cl).requires_grad_() if C2 else None
+    gw, gb = G(w, True), G(b, True)
+    y = ops.Conv3dFn.apply(g1, g2, gw, gb, (st,) * 3)
+    assert y.dtype == BF
+    y.backward(gy.to(DEV).to(BF).contiguous(memory_format=cl))
+    assert torch.equal(y.detach().cpu(), ref.detach().to(BF)), f"{name}: y"
+    assert torch.equal(g1.grad.cpu(), xs[0].grad.to(BF)), f"{name}: dx1"
+    if C2:
+        assert torch.equal(g2.grad.cpu(), xs[1].grad.to(BF)), f"{name}: dx2"
+    assert gw.grad.dtype == torch.float32
+    assert torch.equal(gw.grad.cpu(), wr.grad), f"{name}: dw (max {float((gw.grad.cpu() - wr.grad).abs().max())})"
+    assert torch.equal(gb.grad.cpu(), br.grad), f"{name}: db"
+
+
 @pytest.mark.parametrize("name", list(CONVT))
 def test_cfg2_convT_exact_integer_data(name):
     from multimodal_mvd_seg_amd import ops
