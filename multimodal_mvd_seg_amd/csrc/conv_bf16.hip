@@ -748,6 +748,203 @@ __global__ __launch_bounds__(256, 1) void k_fwd16q(const FwdGeom g, const Fwd16Q
     for (int j = 0; j < 4; j++) epilogue_piece(j >> 1, j & 1);  // the last tile
 }
 
+// ------------------------------------------------------------------------------------------------ k_fwd16r (round 2)
+// EXPERIMENT, not the default path (MVD_FWD16R=1 selects it; measured 9 % slower than k_fwd16q, see launch_fwd16p):
+// k_fwd16q with the halo moved by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write, nothing for the
+// wave to issue but ten 1-KB pieces per tile).  Why it was tried: the ablation of k_fwd16q (tools/bench_conv.py, MVD_FWD16Q_DBG)
+// showed its phases ADDING UP -- MFMA + LDS reads 0.16 ms, halo path +0.065, stores +0.043 -- however the instructions
+// were interleaved: a CU's vector-memory pipe moves ~10 B/clk, a burst of ten register loads per lane fills its queue,
+// and the one wave per SIMD then sits in the VMEM issue stage instead of issuing MFMAs.  Here the pieces of tile t+2 are
+// issued one every other tap of tile t (the pipe's own pace), land in the third of three halo buffers while tile t+1's
+// buffer is complete, and are retired by a counted vmcnt behind tap 24 (the ten newest operations of a wave at that
+// point are exactly its ten pieces of tile t+2; everything older -- tile t+1's pieces, tile t-1's stores -- is done).
+// LDS image: lane-linear per piece (wave-uniform base + 16 * lane), so the XOR swizzle of the 16-byte parts is applied
+// on the SOURCE address: the lane that fills part position pp of a slot fetches part pp ^ (halo row & 3) of that voxel.
+// Zero padding: out-of-volume lanes fetch from a 16-byte zero page.
+__device__ uint4 g_zero_page16 = {0u, 0u, 0u, 0u};
+constexpr int R_BUF = 40 * 1024;  // 600 slots x 64 B rounded up to 40 pieces of 1 KB (4 waves x 10 pieces)
+
+__global__ __launch_bounds__(256, 1) void k_fwd16r(const FwdGeom g, const Fwd16QTile tg, const unsigned short *__restrict__ a1,
+                                                   const unsigned short *__restrict__ w, const float *__restrict__ bias,
+                                                   unsigned short *__restrict__ y1) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds8[];
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    typedef const __attribute__((address_space(1))) unsigned char glb_byte;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = gridDim.x >> 3;
+
+    i32x4 bw[27][2];
+#pragma unroll
+    for (int p = 0; p < 27; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(w + ((size_t)tg.wsel[p] * 128 + (s2 * 2 + h) * 32 + i) * 8);
+            bw[p][s2] = *reinterpret_cast<const i32x4 *>(&q);
+        }
+    // piece u of this wave fills LDS bytes [(u * 4 + wave) * 1024 + 16 * lane, +16): slot = that / 64, part position pp
+    unsigned rel[Q_XR];   // source byte offset from the tile's first halo voxel (interior tiles)
+    int cz[Q_XR];         // halo coordinates of the slot (border tiles), -1: beyond the 600 slots
+#pragma unroll
+    for (int u = 0; u < Q_XR; u++) {
+        const int unit = (u * 4 + wave) * 64 + lane;
+        const int slot = unit >> 2, pp = unit & 3;
+        const int sl = slot < 600 ? slot : 599;
+        const int ez = sl / 100, rem = sl - ez * 100;
+        const int ey = rem / 10, ex = rem - ey * 10;
+        const int q = pp ^ (ey & 3);
+        rel[u] = (unsigned)(((ez * g.Hi + ey) * g.Wi + ex) * 64 + q * 16);
+        cz[u] = slot < 600 ? ((ez << 16) | (ey << 8) | ex | (q << 24)) : -1;
+    }
+    int ra[2][3][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int yl = 4 * m + (i >> 3);
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+                ra[m][dy][s2] = ((wave * 10 + yl) * 10 + (i & 7)) * 64 + ((((s2 << 1) | h) ^ ((yl + dy) & 3)) << 4);
+    }
+    f32x16 biasv;
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b4 = *reinterpret_cast<const float4 *>(bias + 8 * rg + 4 * h);
+        biasv[rg * 4 + 0] = b4.x; biasv[rg * 4 + 1] = b4.y; biasv[rg * 4 + 2] = b4.z; biasv[rg * 4 + 3] = b4.w;
+    }
+    struct TileC { int n, od0, oh0, ow0; };
+    auto decode = [&](int it) {
+        TileC t;
+        unsigned r_ = (unsigned)(xcd * per_xcd + it);
+        t.ow0 = (int)(r_ % (unsigned)tg.ntw) * 8; r_ /= (unsigned)tg.ntw;
+        t.oh0 = (int)(r_ % (unsigned)tg.nth) * 8; r_ /= (unsigned)tg.nth;
+        t.od0 = (int)(r_ % (unsigned)tg.ntd) * 4;
+        t.n = (int)(r_ / (unsigned)tg.ntd);
+        return t;
+    };
+    auto valid = [&](int it) { return it < per_xcd && xcd * per_xcd + it < tg.nitems; };
+    const glb_byte *zero_page = (glb_byte *)(const void *)&g_zero_page16;
+    // one 1-KB piece of tile T's halo into halo buffer `buf`
+    auto dma_piece = [&](const TileC &T, int buf, int u) {
+        const int z0 = T.od0 - 1, y0 = T.oh0 - 1, x0 = T.ow0 - 1;
+        const bool interior = z0 >= 0 && z0 + 6 <= g.Di && y0 >= 0 && y0 + 10 <= g.Hi && x0 >= 0 && x0 + 10 <= g.Wi;
+        const glb_byte *src;
+        if (interior) {  // block-uniform
+            const glb_byte *tb = (glb_byte *)(const void *)a1 + ((((long)T.n * g.Di + z0) * g.Hi + y0) * g.Wi + x0) * 64L;
+            src = tb + rel[u];
+        } else {
+            const int c = cz[u];
+            const int id = z0 + ((c >> 16) & 255), ih = y0 + ((c >> 8) & 255), iw = x0 + (c & 255);
+            const bool in = c >= 0 && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi;
+            const glb_byte *vb = (glb_byte *)(const void *)a1 +
+                                 ((((long)T.n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * 64L + ((c >> 24) & 3) * 16;
+            src = in ? vb : zero_page;
+        }
+        // inline asm, not __builtin_amdgcn_global_load_lds: hipcc (ROCm 7.2) drains every piece with `s_waitcnt vmcnt(0)`
+        // in front of the next ds_read (it models the DMA as an LDS write), which is exactly the serialisation this
+        // kernel exists to remove.  M0 = LDS byte address of the piece, saved / restored around the instruction.
+        lds_byte *dst = (lds_byte *)(lds8 + (size_t)buf * R_BUF + (size_t)(u * 4 + wave) * 1024);
+        const unsigned dsta = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dsta) : "memory");
+    };
+
+    int it = local;
+    if (!valid(it)) return;  // whole workgroup
+    TileC cur_t = decode(it);
+    TileC nxt_t = cur_t, nx2_t = cur_t;
+    bool more = valid(it + nlocal), more2 = valid(it + 2 * nlocal);
+    if (more) nxt_t = decode(it + nlocal);
+#pragma unroll
+    for (int u = 0; u < Q_XR; u++) dma_piece(cur_t, 0, u);
+    if (more) {
+#pragma unroll
+        for (int u = 0; u < Q_XR; u++) dma_piece(nxt_t, 1, u);
+    }
+#pragma unroll
+    for (int p = 0; p < 27; p++) asm volatile("" : "+a"(bw[p][0]), "+a"(bw[p][1]));
+    // tile 0's pieces are older than tile 1's ten: retire them (and everything before), then meet
+    if (more) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    int cur = 0;
+    float pe[2][16];
+    unsigned short *pyo[2] = {nullptr, nullptr};
+    bool have_prev = false;
+    auto epilogue_piece = [&](int m, int kp) {
+        const int k = 2 * kp;
+        const uint4 q = pair_store_image(
+            pack_bf16x4(pe[m][k * 4 + 0], pe[m][k * 4 + 1], pe[m][k * 4 + 2], pe[m][k * 4 + 3]),
+            pack_bf16x4(pe[m][k * 4 + 4], pe[m][k * 4 + 5], pe[m][k * 4 + 6], pe[m][k * 4 + 7]));
+        if (pyo[m]) *reinterpret_cast<uint4 *>(pyo[m] + 8 * k) = q;
+    };
+    i32x4 af[3][2][2];
+    auto read_a = [&](const unsigned char *Xs, int p, int buf) {
+        const int dz = p / 9, dy = (p / 3) % 3, dx = p % 3;
+        const int to = ((dz * 10 + dy) * 10 + dx) * 64;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(Xs + ra[m][dy][s2] + to);
+                af[buf][m][s2] = *reinterpret_cast<const i32x4 *>(&q);
+            }
+    };
+    read_a(lds8, 0, 0);
+    read_a(lds8, 1, 1);
+    while (true) {
+        if (more2) nx2_t = decode(it + 2 * nlocal);
+        const int b2 = cur >= 1 ? cur - 1 : 2;  // (cur + 2) % 3: read last during the PREVIOUS tile, free since its barrier
+        const int b1 = cur == 2 ? 0 : cur + 1;  // (cur + 1) % 3
+        const unsigned char *Xs = lds8 + (size_t)cur * R_BUF;
+        const unsigned char *Xn = lds8 + (size_t)b1 * R_BUF;
+        f32x16 acc[2] = {biasv, biasv};
+#pragma unroll
+        for (int p = 0; p < 27; p++) {
+            if (p + 2 < 27) read_a(Xs, p + 2, (p + 2) % 3);
+            else if (more) read_a(Xn, p + 2 - 27, (p + 2) % 3);  // next tile's taps 0, 1 (behind the barrier of tap 24)
+            if (p < 4 && have_prev) epilogue_piece(p >> 1, p & 1);                       // stores first ...
+            if (p >= 4 && p <= 22 && !(p & 1) && more2) dma_piece(nx2_t, b2, (p - 4) >> 1);  // ... then the ten pieces
+            if (p == 24 && more) {
+                // the ten newest vector-memory operations of this wave are its pieces of tile t+2 (none if there is no
+                // such tile): everything older, i.e. the next tile's halo and the previous tile's stores, has landed
+                if (more2) asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int m = 0; m < 2; m++) MVD_MFMA16_AB(acc[m], bw[p][s2], af[p % 3][m][s2]);
+        }
+        asm volatile("s_nop 7\n\ts_nop 4" : "+a"(acc[0]), "+a"(acc[1]));
+        {
+            const int od = cur_t.od0 + wave;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) pe[m][r] = acc[m][r];
+                const int oh = cur_t.oh0 + 4 * m + (i >> 3), ow = cur_t.ow0 + (i & 7);
+                pyo[m] = (od < g.Do && oh < g.Ho && ow < g.Wo)
+                             ? y1 + ((((size_t)cur_t.n * g.Dy + od) * g.Hy + oh) * g.Wy + ow) * 32 + 8 * h
+                             : nullptr;
+            }
+            have_prev = true;
+        }
+        if (!more) break;
+        cur = b1;
+        it += nlocal;
+        cur_t = nxt_t;
+        nxt_t = nx2_t;
+        more = more2;
+        more2 = valid(it + 2 * nlocal);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) epilogue_piece(j >> 1, j & 1);  // the last tile
+}
+
 static int num_cus16() {
     static int n = 0;
     if (!n) {
@@ -802,6 +999,22 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
                 if (g.off[t][0] == dz && g.off[t][1] == dy && g.off[t][2] == dx) hit = t;
             if (hit < 0) ok = false;
             else tq.wsel[p] = g.wt[hit];
+        }
+        // measured (round 2, enc0.conv1 dgrad, bench_conv --iters 40): k_fwd16r 0.282 ms, k_fwd16q 0.258 ms -- the DMA
+        // pieces cost the wave more issue time than ten register loads + ten ds_write_b128.  Selectable, off by default.
+        static const int use_r = getenv("MVD_FWD16R") ? atoi(getenv("MVD_FWD16R")) : 0;
+        if (ok && use_r) {
+            static bool configured_r = false;
+            if (!configured_r) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd16r), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_LIMIT16) != hipSuccess) {
+                    set_error("conv fwd16r: cannot raise the dynamic LDS limit");
+                    return 1;
+                }
+                configured_r = true;
+            }
+            hipLaunchKernelGGL(k_fwd16r, dim3((unsigned)ncu), dim3(Q_TPB), 3 * (size_t)R_BUF, s, g, tq, a1, w, bias, y1);
+            return check_launch("conv fwd16r (persistent bf16 mfma, LDS-DMA halo)");
         }
         if (ok) {
             static const int dbgq = getenv("MVD_FWD16Q_DBG") ? atoi(getenv("MVD_FWD16Q_DBG")) & 15 : 0;
