@@ -2105,6 +2105,31 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
     const int part = tid & 3;
 
     uint4 ra[NA], rb[NB];
+    // tile-independent decode of this thread's staging slots (round 2): element offset from the tile's first halo voxel
+    // and packed halo coordinates.  load_tile used to redo the slot -> (z, y, x) decode, six bounds compares and a 64-bit
+    // address per 16-byte load for every tile: ~270 VALU instructions per tile and wave next to 56 MFMAs.  Interior
+    // tiles (no halo voxel outside the volume; the majority) now load from scalar base + lane offset with no bounds
+    // logic; border tiles test the precomputed coordinates.
+    int relA[NA], czA[NA], relB[NB], czB[NB];
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx < na ? (idx >> 2) : 0;
+        const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
+        const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
+        relA[u] = ((ez * g.Hi + ey) * g.Wi + ex) * Cs + part * 8;
+        czA[u] = idx < na ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx < nb ? (idx >> 2) : 0;
+        const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
+        const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
+        relB[u] = ((ez * g.Hb + ey) * g.Wb + ex) * K + part * 8;
+        czB[u] = idx < nb ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+    const int EAd = (tg.nslotsA / EAhw), EBd = (tg.nslotsB / EBhw);  // halo extents along D
     auto load_tile = [&](int tile) {
         unsigned r_ = (unsigned)tile;
         const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
@@ -2114,32 +2139,38 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
         const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
         {
             const int z0 = od0 * g.sa[0] + tg.minA[0], y0 = oh0 * g.sa[1] + tg.minA[1], x0 = ow0 * g.sa[2] + tg.minA[2];
+            const bool interior = z0 >= 0 && z0 + EAd <= g.Di && y0 >= 0 && y0 + tg.EAh <= g.Hi && x0 >= 0 && x0 + tg.EAw <= g.Wi;
+            const unsigned short *base = asrc + ((((long)n * g.Di + z0) * g.Hi + y0) * g.Wi + x0) * (long)Cs + cofs;
+            if (interior) {  // block-uniform
 #pragma unroll
-            for (int u = 0; u < NA; u++) {
-                const int idx = u * 256 + tid;
-                const int slot = idx >> 2;
-                const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
-                const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
-                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
-                ra[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (idx < na && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
-                    ra[u] = *reinterpret_cast<const uint4 *>(
-                        asrc + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + part * 8);
+                for (int u = 0; u < NA; u++) ra[u] = *reinterpret_cast<const uint4 *>(base + relA[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < NA; u++) {
+                    const int c = czA[u];
+                    const int id = z0 + (c >> 16), ih = y0 + ((c >> 8) & 255), iw = x0 + (c & 255);
+                    ra[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (c >= 0 && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                        ra[u] = *reinterpret_cast<const uint4 *>(base + relA[u]);
+                }
             }
         }
         {
             const int z0 = od0 * g.sb[0] + tg.minB[0], y0 = oh0 * g.sb[1] + tg.minB[1], x0 = ow0 * g.sb[2] + tg.minB[2];
+            const bool interior = z0 >= 0 && z0 + EBd <= g.Db && y0 >= 0 && y0 + tg.EBh <= g.Hb && x0 >= 0 && x0 + tg.EBw <= g.Wb;
+            const unsigned short *base = b + ((((long)n * g.Db + z0) * g.Hb + y0) * g.Wb + x0) * (long)K + k0;
+            if (interior) {
 #pragma unroll
-            for (int u = 0; u < NB; u++) {
-                const int idx = u * 256 + tid;
-                const int slot = idx >> 2;
-                const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
-                const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
-                const int id = z0 + ez, ih = y0 + ey, iw = x0 + ex;
-                rb[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (idx < nb && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
-                    rb[u] = *reinterpret_cast<const uint4 *>(
-                        b + ((((size_t)n * g.Db + id) * g.Hb + ih) * g.Wb + iw) * K + k0 + part * 8);
+                for (int u = 0; u < NB; u++) rb[u] = *reinterpret_cast<const uint4 *>(base + relB[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < NB; u++) {
+                    const int c = czB[u];
+                    const int id = z0 + (c >> 16), ih = y0 + ((c >> 8) & 255), iw = x0 + (c & 255);
+                    rb[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (c >= 0 && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
+                        rb[u] = *reinterpret_cast<const uint4 *>(base + relB[u]);
+                }
             }
         }
     };
@@ -2161,6 +2192,24 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
     }
     constexpr int NAV = SH == 2 ? 1 : TPW, NBV = SH == 1 ? 1 : TPW;
 
+    // Per-step operand row offsets (A rows r = 0, 1; B rows r = 0, 1) of every lane, once per workgroup, in LDS: the
+    // inner loop used to recompute them -- 56 of its ~90 VALU instructions per 7 MFMAs (PMC round 2: 13 VALU per MFMA,
+    // MFMA pipe 33 % busy) -- now it is one ds_read_b128 per step.
+    int4 *steptab = reinterpret_cast<int4 *>(lds8 + (size_t)(NA + NB) * 4096);
+    for (int e = tid; e < (TV >> 4) * 64; e += 256) {
+        const int st = e >> 6, l = e & 63;
+        const int hh = l >> 5, qq = (l & 15) >> 2;
+        int t4[4];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int v = st * 16 + 8 * hh + 4 * r + qq;
+            const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
+            t4[r] = (((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2]) * 64;
+            t4[2 + r] = (((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2]) * 64;
+        }
+        steptab[e] = make_int4(t4[0], t4[1], t4[2], t4[3]);
+    }
+
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
     while (tile < tg.ntiles) {
@@ -2170,14 +2219,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
         const int next = tile + tg.nsplit;
         if (next < tg.ntiles) load_tile(next);
         for (int s16 = 0; s16 < TV; s16 += 16) {  // TV is a multiple of 16 for every tile shape
-            int sa_[2], sb_[2];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int v = s16 + 8 * h + 4 * r + q4;
-                const int wx = v & (tg.TW - 1), hy = (v >> tg.lTW) & (tg.TH - 1), dz = v >> (tg.lTW + tg.lTH);
-                sa_[r] = (((dz * g.sa[0]) * tg.EAh + hy * g.sa[1]) * tg.EAw + wx * g.sa[2]) * 64;
-                sb_[r] = (((dz * g.sb[0]) * tg.EBh + hy * g.sb[1]) * tg.EBw + wx * g.sb[2]) * 64;
-            }
+            const int4 t4 = steptab[(s16 >> 4) * 64 + lane];
+            const int sa_[2] = {t4.x, t4.y}, sb_[2] = {t4.z, t4.w};
             bf16x8w av[NAV], bv[NBV];
 #pragma unroll
             for (int j = 0; j < NAV; j++) av[j] = tr_operand(As + sa_[0] + aoff[j], As + sa_[1] + aoff[j]);
@@ -2377,7 +2420,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         const unsigned short *h2 = reinterpret_cast<const unsigned short *>(a2);
         const unsigned short *hb = reinterpret_cast<const unsigned short *>(b);
 #define WG16(TPW, NA, NB, SH) \
-    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096, s, g, tg, h1, h2, hb, partial)
+    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096 + 8192, s, g, tg, h1, h2, hb, partial)
 #define WG16_TPW(NA, NB, SH)                  \
     {                                         \
         if (tpw <= 1) WG16(1, NA, NB, SH);    \
