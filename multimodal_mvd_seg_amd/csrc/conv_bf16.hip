@@ -945,6 +945,330 @@ __global__ __launch_bounds__(256, 1) void k_fwd16r(const FwdGeom g, const Fwd16Q
     for (int j = 0; j < 4; j++) epilogue_piece(j >> 1, j & 1);  // the last tile
 }
 
+// ------------------------------------------------------------------------------------------------ k_fwd16z (round 2)
+// z-marching form of the 32 -> 32 channel 3x3x3 stride-1 convolution (same shape class as k_fwd16q).  What k_fwd16q's
+// ablation left as the bound was the traffic a 4x8x8 tile pulls through the CU's vector-memory pipe (a 6x10x10 halo:
+// 2.34 bytes fetched per byte used) with one wave per SIMD to issue it.  Here a workgroup owns an 8 x 32 (y, x) column
+// and walks a chunk of z-planes:
+//   * input plane z' arrives once (10 x 34 voxels: 1.33 bytes fetched per byte used, rows of 2 KB contiguous in HBM),
+//     register-staged one plane ahead into a ring of four LDS plane images;
+//   * every A fragment read from LDS (input row r, x shift dx, k-step) feeds up to SIX MFMAs: the three dz taps -- they
+//     accumulate into three different OUTPUT planes z'+1, z', z'-1, held as a ring of four accumulator sets, so no
+//     partial sum ever moves -- times the one or two M tiles (output rows) of the wave that see row r at some dy:
+//     24 ds_read_b128 per 108 MFMAs (k_fwd16q: 108);
+//   * a wave = two M tiles (two output rows of 32 voxels), the 27 taps' B fragments resident in the accumulator half of
+//     the register file as in k_fwd16q; the plane loop is unrolled four times so that ring positions are register names
+//     and LDS offsets are immediates;
+//   * the output plane completed by plane z' is converted between the MFMAs of plane z'+1 (fourth set), transposed
+//     through a 4-KB per-wave LDS scratch and stored as four fully contiguous 1-KB wave stores; the drained set is then
+//     re-initialised with the bias from an LDS table (ds_read_b128 straight into the accumulator registers).
+// With one wave per SIMD nothing hides behind another wave: everything that is not an MFMA is either precomputed per
+// column (the column is fixed for the life of the workgroup), an immediate, a range-checked buffer access (zeros outside
+// the plane / dropped stores: no selects, no branches) or dealt out over the 24 fragment slots of a plane.
+// A-operand LDS image of a plane: two sub-images (k-step 0: channels 0-15, k-step 1: 16-31) of 340 slots x 32 bytes; the
+// two 16-byte halves of a slot are swapped when (slot >> 3) & 1: the 16 lanes of a ds_read_b128 group ({0-3,12-15,20-27},
+// ...) read slots whose (slot mod 8) picks the 32-byte column of the 256-byte bank row, and the two lanes that share a
+// column are 8 or 24 slots apart -- conflict-free for every dx; the k-step is an immediate offset.
+constexpr int Z_ROWS = 10, Z_SLOTS = 34, Z_NSLOT = Z_ROWS * Z_SLOTS, Z_XR = 6, Z_PARTS = Z_NSLOT * 4;
+constexpr int Z_HALF = Z_NSLOT * 32 + 64;      // +64: the two sub-images of a slot pair land on different write banks
+constexpr int Z_PLANE = Z_HALF + Z_NSLOT * 32;
+constexpr int Z_SCR = 4 * Z_PLANE, Z_BIAS = Z_SCR + 4 * 4096, Z_LDS = Z_BIAS + 4096;
+static_assert(Z_PLANE + Z_HALF < 65536, "plane / k-step offsets must fit the 16-bit ds_read immediate");
+
+struct Fwd16ZTile {
+    int nty, ntx, nzc, zc, nitems;
+    int wsel[27];
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+typedef __attribute__((address_space(3))) u32x2 lds_u2;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ inline unsigned cvt_pk_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32 (round-to-nearest-even, as f2bf)
+    f32x2 v = {a, b};
+    bf16x2v r = __builtin_convertvector(v, bf16x2v);
+    return *reinterpret_cast<unsigned *>(&r);
+}
+
+// A fragments come straight from ds_read_b128 (no VALU-written operand): no wait states needed in front of the MFMA
+#define MVD_MFMA16_ZV(ACC, BFRAG, AFRAG) \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "a"(BFRAG), "v"(AFRAG))
+
+template <int R>
+struct ZIdx { static constexpr int value = R; };
+
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16ZTile tg, const unsigned short *__restrict__ a1,
+                                                   const unsigned short *__restrict__ w, const float *__restrict__ bias,
+                                                   unsigned short *__restrict__ y1) {
+    constexpr int dbg = DBG;  // 1: no global loads / LDS writes after the prologue, 2: no MFMAs, 4: no stores, 8: no epilogue,
+                              // 16: no barrier, 32: no A-fragment reads after the prologue (ablation builds; results wrong)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    // XCD-aware item order: each XCD walks a contiguous range of (n, chunk, ty, tx) -- neighbours share halo rows in its L2
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= tg.nitems) return;
+    unsigned r_ = (unsigned)item;
+    const int tx = (int)(r_ % (unsigned)tg.ntx); r_ /= (unsigned)tg.ntx;
+    const int ty = (int)(r_ % (unsigned)tg.nty); r_ /= (unsigned)tg.nty;
+    const int zchunk = (int)(r_ % (unsigned)tg.nzc);
+    const int n_ = (int)(r_ / (unsigned)tg.nzc);
+    const int y0 = ty * 8, x0 = tx * 32, zb = zchunk * tg.zc;
+    const int ze = min(zb + tg.zc, g.Do);
+
+    i32x4 bw[27][2];
+#pragma unroll
+    for (int p = 0; p < 27; p++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(w + ((size_t)tg.wsel[p] * 128 + (s2 * 2 + h) * 32 + i) * 8);
+            bw[p][s2] = *reinterpret_cast<const i32x4 *>(&q);
+        }
+    // staging slots (column constants): byte offset inside an input plane -- 0xfffffff0 for parts outside the (y, x) plane:
+    // the plane is read through a buffer descriptor whose range check returns zeros there (no select, no branch) -- and
+    // the LDS offset
+    unsigned rel[Z_XR], wa[Z_XR];
+#pragma unroll
+    for (int u = 0; u < Z_XR; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx < Z_PARTS ? (idx >> 2) : 0;
+        const int ry = slot / Z_SLOTS, sx = slot - ry * Z_SLOTS;
+        const int gy = y0 - 1 + ry, gx = x0 - 1 + sx;
+        const bool in = idx < Z_PARTS && gy >= 0 && gy < g.Hi && gx >= 0 && gx < g.Wi;
+        const int part = idx & 3;
+        rel[u] = in ? (unsigned)((gy * g.Wi + gx) * 64 + part * 16) : 0xfffffff0u;
+        wa[u] = lbase + (part >> 1) * Z_HALF + slot * 32 + (((part & 1) ^ ((slot >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int u = 0; u < Z_XR; u++) asm volatile("" : "+v"(rel[u]), "+v"(wa[u]));  // one register each, no re-derivation per plane
+    // A-operand read addresses: input row r of this wave, x shift dx (k-step and image parity are immediates; images 2, 3
+    // lie beyond the 16-bit immediate: one v_add per read there -- a second set of 12 address registers spilled)
+    unsigned ra[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int slot = (2 * wave + r) * Z_SLOTS + dx + i;
+            ra[r][dx] = lbase + slot * 32 + ((h ^ ((slot >> 3) & 1)) << 4);
+            asm volatile("" : "+v"(ra[r][dx]));
+        }
+    // the bias in accumulator layout (register r <-> output channel (r & 3) + 8 * (r >> 2) + 4 * h) lives in LDS, 16 bytes
+    // per lane and register group: a drained accumulator set is re-initialised from there by four ds_read_b128 per M tile,
+    // dealt out over fragment slots (no VALU; as the C operand of a first MFMA it would cost 16 arch VGPRs the kernel
+    // does not have)
+    unsigned bsc = lbase + Z_BIAS + lane * 16;
+    asm volatile("" : "+v"(bsc));
+    {
+        u32x4 bq[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) b4 = *reinterpret_cast<const float4 *>(bias + 8 * rg + 4 * h);
+            bq[rg] = u32x4{__float_as_uint(b4.x), __float_as_uint(b4.y), __float_as_uint(b4.z), __float_as_uint(b4.w)};
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) *(lds_u4 *)(bsc + rg * 1024) = bq[rg];
+        }
+    }
+    // output transposition through the wave's 4-KB scratch: lane (i, h) holds, per M tile m and register group rg, the 4
+    // channels 8 rg + 4 h .. +3 of voxel i (8 bytes packed) -> scratch [m][voxel][64 B] with the 16-byte units XORed by
+    // (voxel >> 1) & 3 (ds_write_b64, 2-way conflicts: 8 LDS cycles against 6 of transfer); read back as lane L = 16-byte
+    // chunk L & 3 of voxel 16 (q & 1) + L / 4 of row q >> 1 (conflict-free) = 1 KB contiguous in HBM per wave store
+    const unsigned scr = lbase + Z_SCR + wave * 4096;
+    unsigned wsc[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) wsc[rg] = scr + i * 64 + ((rg ^ ((i >> 1) & 3)) << 4) + h * 8;
+    unsigned rsc = scr + (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) << 4);
+    asm volatile("" : "+v"(rsc), "+v"(wsc[0]), "+v"(wsc[1]), "+v"(wsc[2]), "+v"(wsc[3]));
+    // byte offset of this lane's chunk inside an output plane for store q (row q >> 1, voxels 16 (q & 1) ..): out of range
+    // (dropped by the descriptor's range check) when the voxel lies outside the volume
+    unsigned voff[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int oh = y0 + 2 * wave + (q >> 1), ow = x0 + (q & 1) * 16 + (lane >> 2);
+        voff[q] = (oh < g.Ho && ow < g.Wo) ? (unsigned)((oh * g.Wy + ow) * 64 + (lane & 3) * 16) : 0xfffffff0u;
+    }
+    asm volatile("" : "+v"(voff[0]), "+v"(voff[1]), "+v"(voff[2]), "+v"(voff[3]));
+    const size_t oplane = (size_t)g.Hy * g.Wy * 64;
+    char *ybase = reinterpret_cast<char *>(y1) + (size_t)n_ * g.Dy * oplane;
+    const char *abase = reinterpret_cast<const char *>(a1) + (size_t)n_ * g.Di * g.Hi * g.Wi * 64;
+    const size_t iplane = (size_t)g.Hi * g.Wi * 64;
+    const unsigned iplane32 = (unsigned)iplane, oplane32 = (unsigned)oplane;
+
+    // plane index j <-> input plane z' = zb - 1 + j; planes 0 .. nproc-1 carry MFMAs (when inside the volume), plane
+    // nproc only drains the last output plane
+    const int nproc = (ze - zb) + 2;
+    auto zin = [&](int j) { return zb - 1 + j; };
+    auto live = [&](int j) { const int z = zin(j); return j < nproc && z >= 0 && z < g.Di; };  // block-uniform
+    u32x4 v[Z_XR];
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(abase), 0, 0, 0x00020000);
+    auto set_in_plane = [&](int j) {  // descriptor of input plane zin(j) (uniform)
+        rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(abase + (size_t)zin(j) * iplane), 0, (int)iplane32, 0x00020000);
+    };
+    auto stage_load = [&](int u) { v[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)rel[u], 0, 0); };
+    auto stage_write = [&](unsigned imgoff, int u) {
+        if (u < Z_XR - 1 || tid < Z_PARTS - (Z_XR - 1) * 256) *(lds_u4 *)(wa[u] + imgoff) = v[u];
+    };
+    auto load_plane = [&](int j) {
+        set_in_plane(j);
+#pragma unroll
+        for (int u = 0; u < Z_XR; u++) stage_load(u);
+    };
+    auto store_plane = [&](unsigned imgoff) {
+#pragma unroll
+        for (int u = 0; u < Z_XR; u++) stage_write(imgoff, u);
+    };
+    i32x4 af[3];  // ring of three A fragments, fetched two fragments ahead (also across planes)
+    // fragment f = (r * 3 + dx) * 2 + ks of plane image IMG
+#define MVD_Z_READ_A(IMG, F, BUF)                                                                                    \
+    {                                                                                                                \
+        const u32x4 q_ = *(lds_u4 *)(ra[(F) / 6][((F) >> 1) % 3] + (IMG) * Z_PLANE + ((F) & 1) * Z_HALF);            \
+        af[BUF] = *reinterpret_cast<const i32x4 *>(&q_);                                                             \
+    }
+
+    f32x16 S[4][2];  // accumulator ring: output plane zo lives in S[(zo - zb + 1) & 3]
+    auto bias_init = [&](f32x16 &acc, int rg) {  // acc[4 rg .. 4 rg + 3] = bias
+        const u32x4 q = *(lds_u4 *)(bsc + rg * 1024);
+        acc[rg * 4 + 0] = __uint_as_float(q.x); acc[rg * 4 + 1] = __uint_as_float(q.y);
+        acc[rg * 4 + 2] = __uint_as_float(q.z); acc[rg * 4 + 3] = __uint_as_float(q.w);
+    };
+    if (live(0)) {
+        load_plane(0);
+        store_plane(0);
+    }
+    if (live(1)) load_plane(1);
+#pragma unroll
+    for (int p = 0; p < 27; p++) asm volatile("" : "+a"(bw[p][0]), "+a"(bw[p][1]));
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 32; q++) bias_init(S[q >> 3][(q >> 2) & 1], q & 3);
+    if (live(0)) {
+        MVD_Z_READ_A(0, 0, 0);
+        MVD_Z_READ_A(0, 1, 1);
+    }
+
+    // plane j with ring position R = j & 3: input image R, accumulator sets NEW = R (output plane z'+1: first
+    // contribution, holds the bias), MID = R-1 (z'), OLD = R-2 (z'-1: complete after this plane), DRAIN = R-3 (z'-2:
+    // completed by the previous plane, stored during this one, then reset to the bias: it is the next plane's NEW).
+    // STEADY planes (all but the first four and the last few of a chunk): this plane, the next two and the drained output
+    // plane all exist -- no flags, no branches; the few scalar instructions a plane needs (two descriptors) sit in fragment
+    // slots.  Ablation (MVD_FWD16Z_DBG=61: MFMAs only) had shown 38.7 cycles per MFMA against 32.4 for the bare loop: ~60
+    // scalar instructions and five branches evaluating plane flags in one clump at every plane boundary -- an in-order wave
+    // issues no MFMA behind them.
+    auto plane = [&](auto Rc, auto Sc, int j) __attribute__((always_inline)) {
+        constexpr int R = decltype(Rc)::value;
+        constexpr bool STEADY = decltype(Sc)::value != 0;
+        constexpr int NEW = R, MID = (R + 3) & 3, OLD = (R + 2) & 3, DRN = (R + 1) & 3, RN = (R + 1) & 3;
+        const bool cur = STEADY || live(j), nxt = STEADY || live(j + 1), nxt2 = STEADY || live(j + 2);
+        const int zo = zin(j) - 2;  // the plane held by DRN
+        const bool st = (STEADY || (zo >= zb && zo < ze)) && !(dbg & 4);
+        // descriptor of the output plane; zero records when this set is not an output plane of the chunk: the four stores
+        // are then dropped by the range check (no branch)
+        __amdgpu_buffer_rsrc_t rout;
+        auto set_out_plane = [&]() {
+            rout = __builtin_amdgcn_make_buffer_rsrc(ybase + (size_t)(STEADY ? zo : max(zo, 0)) * oplane, 0,
+                                                     st ? (int)oplane32 : 0, 0x00020000);
+        };
+        if (!STEADY) set_out_plane();
+        auto epi_pack = [&](int m, int rg) {  // 2 conversions + 1 ds_write_b64
+            u32x2 q;
+            q.x = cvt_pk_bf16(S[DRN][m][rg * 4 + 0], S[DRN][m][rg * 4 + 1]);
+            q.y = cvt_pk_bf16(S[DRN][m][rg * 4 + 2], S[DRN][m][rg * 4 + 3]);
+            *(lds_u2 *)(wsc[rg] + m * 2048) = q;
+        };
+        u32x4 ob;
+        auto epi_read = [&](int q) { ob = *(lds_u4 *)(rsc + q * 1024); };
+        auto epi_store = [&](int q) { __builtin_amdgcn_raw_buffer_store_b128(ob, rout, (int)voff[q], 0, 0); };
+        constexpr unsigned IMGN = RN * Z_PLANE;
+        const bool do_w = nxt && !(dbg & 1), do_l = nxt2 && !(dbg & 1);
+        if (!STEADY && do_l) set_in_plane(j + 2);
+        if (cur) {
+            // everything that is not an MFMA is dealt out over the 24 fragment slots of the plane (an MFMA leaves ~24 issue
+            // cycles per 32; a clump in front of the plane is paid in full):
+            //   f 0-5   one staging ds_write_b128 (plane j+1, loaded during plane j-1) each
+            //   f 1-4   epilogue of the drained set: 4 conversions + 2 ds_write_b64 each
+            //   f 6-11  one global load (plane j+2) each;   f 6-13 scratch read-back and one 1-KB output store, alternating
+            //   f 14-21 one ds_read_b128 of the bias table into the drained set each
+            //   f 18    barrier (plane j+1 visible);        f 22-23 first fragments of plane j+1
+#pragma unroll
+            for (int f = 0; f < 24; f++) {
+                if (dbg & 32) {
+                } else if (f + 2 < 24) MVD_Z_READ_A(R, f + 2, (f + 2) % 3)
+                else if (nxt) MVD_Z_READ_A(RN, f + 2 - 24, (f + 2) % 3)  // behind the barrier below
+                if (f < 6 && do_w) stage_write(IMGN, f);
+                if (STEADY && f == 4) set_out_plane();
+                if (STEADY && f == 5 && do_l) set_in_plane(j + 2);
+                if (f == 1) asm volatile("" : "+v"(S[DRN][0]), "+v"(S[DRN][1]));  // keeps the conversions in their slots
+                if (f >= 1 && f <= 4 && !(dbg & 8)) {
+                    epi_pack((f - 1) >> 1, ((f - 1) & 1) * 2);
+                    epi_pack((f - 1) >> 1, ((f - 1) & 1) * 2 + 1);
+                }
+                if (f >= 6 && f < 12 && do_l) stage_load(f - 6);
+                if (f >= 6 && f < 14 && !(f & 1) && !(dbg & 8)) epi_read((f - 6) >> 1);
+                if (f >= 6 && f < 14 && (f & 1) && !(dbg & 8)) epi_store((f - 7) >> 1);
+                if (f >= 14 && f < 22) bias_init(S[DRN][(f - 14) >> 2], (f - 14) & 3);  // the next plane's NEW set
+                if (f == 18 && !(dbg & 16)) asm volatile("s_barrier" ::: "memory");  // this wave's plane writes retired in
+                                                                                       // order before the reads consumed above
+                const int r = f / 6, dx = (f >> 1) % 3, ks = f & 1;
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    const int dy = r - m;  // input row r is output row m shifted by dy - 1
+                    if (dy < 0 || dy > 2) continue;
+                    if (dbg & 2) continue;
+                    MVD_MFMA16_ZV(S[NEW][m], bw[0 * 9 + dy * 3 + dx][ks], af[f % 3]);
+                    MVD_MFMA16_ZV(S[MID][m], bw[1 * 9 + dy * 3 + dx][ks], af[f % 3]);
+                    MVD_MFMA16_ZV(S[OLD][m], bw[2 * 9 + dy * 3 + dx][ks], af[f % 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // an MFMA result needs 12 wait states before anything but an accumulating MFMA reads it
+            asm volatile("s_nop 7\n\ts_nop 4" : "+v"(S[OLD][0]), "+v"(S[OLD][1]));
+        } else {
+            if (do_w) store_plane(IMGN);
+            if (do_l) {
+#pragma unroll
+                for (int u = 0; u < Z_XR; u++) stage_load(u);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) epi_pack(q >> 2, q & 3);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { epi_read(q); epi_store(q); }
+#pragma unroll
+            for (int q = 0; q < 8; q++) bias_init(S[DRN][q >> 2], q & 3);
+            __syncthreads();
+            if (nxt) {
+                MVD_Z_READ_A(RN, 0, 0);
+                MVD_Z_READ_A(RN, 1, 1);
+            }
+        }
+    };
+    const int jhi = min(nproc, g.Di - zb + 1);  // live(j) <=> jlo <= j < jhi with jlo <= 1
+    for (int j = 0; j <= nproc; j += 4) {
+        if (j >= 4 && j + 5 < jhi) {  // planes j .. j+3 are steady (j+3+2 is live; their drained planes belong to the chunk)
+            plane(ZIdx<0>(), ZIdx<1>(), j);
+            plane(ZIdx<1>(), ZIdx<1>(), j + 1);
+            plane(ZIdx<2>(), ZIdx<1>(), j + 2);
+            plane(ZIdx<3>(), ZIdx<1>(), j + 3);
+            continue;
+        }
+        plane(ZIdx<0>(), ZIdx<0>(), j);
+        if (j + 1 > nproc) break;
+        plane(ZIdx<1>(), ZIdx<0>(), j + 1);
+        if (j + 2 > nproc) break;
+        plane(ZIdx<2>(), ZIdx<0>(), j + 2);
+        if (j + 3 > nproc) break;
+        plane(ZIdx<3>(), ZIdx<0>(), j + 3);
+    }
+#undef MVD_Z_READ_A
+}
+
 static int num_cus16() {
     static int n = 0;
     if (!n) {
@@ -1002,6 +1326,57 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
         }
         // measured (round 2, enc0.conv1 dgrad, bench_conv --iters 40): k_fwd16r 0.282 ms, k_fwd16q 0.258 ms -- the DMA
         // pieces cost the wave more issue time than ten register loads + ten ds_write_b128.  Selectable, off by default.
+        static const int use_z = getenv("MVD_FWD16Z") ? atoi(getenv("MVD_FWD16Z")) : 0;
+        if (ok && use_z) {
+            Fwd16ZTile tz;
+            memset(&tz, 0, sizeof(tz));
+            memcpy(tz.wsel, tq.wsel, sizeof(tz.wsel));
+            tz.nty = (g.Ho + 7) / 8;
+            tz.ntx = (g.Wo + 31) / 32;
+            // z chunks: enough workgroups to fill the chip in whole rounds, chunks of >= 8 planes (2 extra input planes
+            // and two partly useful MFMA planes per chunk)
+            const long cols = (long)g.N * tz.nty * tz.ntx;
+            int best = 1;
+            double best_cost = 1e30;
+            for (int nz = 1; nz <= (g.Do + 7) / 8; nz++) {
+                const int zc = (g.Do + nz - 1) / nz;
+                const long wgs = cols * ((g.Do + zc - 1) / zc);
+                const double cost = (double)((wgs + ncu - 1) / ncu) * (zc + 2.5);
+                if (cost < best_cost - 1e-9) { best_cost = cost; best = nz; }
+            }
+            tz.zc = (g.Do + best - 1) / best;
+            tz.nzc = (g.Do + tz.zc - 1) / tz.zc;
+            tz.nitems = (int)(cols * tz.nzc);
+            static const int dbgz = getenv("MVD_FWD16Z_DBG") ? atoi(getenv("MVD_FWD16Z_DBG")) & 63 : 0;
+            typedef void (*kz_t)(const FwdGeom, const Fwd16ZTile, const unsigned short *, const unsigned short *, const float *,
+                                 unsigned short *);
+            kz_t kfn = k_fwd16z<0>;
+            switch (dbgz) {
+                case 1: kfn = k_fwd16z<1>; break;
+                case 2: kfn = k_fwd16z<2>; break;
+                case 4: kfn = k_fwd16z<4>; break;
+                case 5: kfn = k_fwd16z<5>; break;
+                case 13: kfn = k_fwd16z<13>; break;
+                case 29: kfn = k_fwd16z<29>; break;
+                case 61: kfn = k_fwd16z<61>; break;
+                case 21: kfn = k_fwd16z<21>; break;
+                case 37: kfn = k_fwd16z<37>; break;
+                default: break;
+            }
+            static bool configured_z = false;
+            if (!configured_z) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z_LDS);
+                if (e != hipSuccess) {
+                    set_error("conv fwd16z: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+                    return 1;
+                }
+                configured_z = true;
+            }
+            const int per_xcd = (tz.nitems + 7) / 8;
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(per_xcd * 8)), dim3(256), (size_t)Z_LDS, s, g, tz, a1, w, bias, y1);
+            return check_launch("conv fwd16z (z-marching bf16 mfma, weights in registers)");
+        }
         static const int use_r = getenv("MVD_FWD16R") ? atoi(getenv("MVD_FWD16R")) : 0;
         if (ok && use_r) {
             static bool configured_r = false;
