@@ -951,7 +951,8 @@ __global__ __launch_bounds__(256, 1) void k_fwd16r(const FwdGeom g, const Fwd16Q
 // 2.34 bytes fetched per byte used) with one wave per SIMD to issue it.  Here a workgroup owns an 8 x 32 (y, x) column
 // and walks a chunk of z-planes:
 //   * input plane z' arrives once (10 x 34 voxels: 1.33 bytes fetched per byte used, rows of 2 KB contiguous in HBM),
-//     register-staged one plane ahead into a ring of four LDS plane images;
+//     register-staged (two planes in flight: loaded three planes ahead of its MFMAs -- one plane ahead left the loaded
+//     HBM latency exposed) into a ring of four LDS plane images;
 //   * every A fragment read from LDS (input row r, x shift dx, k-step) feeds up to SIX MFMAs: the three dz taps -- they
 //     accumulate into three different OUTPUT planes z'+1, z', z'-1, held as a ring of four accumulator sets, so no
 //     partial sum ever moves -- times the one or two M tiles (output rows) of the wave that see row r at some dy:
@@ -1004,7 +1005,9 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
                                                    const unsigned short *__restrict__ w, const float *__restrict__ bias,
                                                    unsigned short *__restrict__ y1) {
     constexpr int dbg = DBG;  // 1: no global loads / LDS writes after the prologue, 2: no MFMAs, 4: no stores, 8: no epilogue,
-                              // 16: no barrier, 32: no A-fragment reads after the prologue (ablation builds; results wrong)
+                              // 16: no barrier, 32: no A-fragment reads after the prologue, 64: descriptors not updated,
+                              // 128: no buffer loads / stores issued, 256: no bias re-initialisation (ablation builds;
+                              // results wrong)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds8;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1107,23 +1110,24 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
     const int nproc = (ze - zb) + 2;
     auto zin = [&](int j) { return zb - 1 + j; };
     auto live = [&](int j) { const int z = zin(j); return j < nproc && z >= 0 && z < g.Di; };  // block-uniform
-    u32x4 v[Z_XR];
+    u32x4 v[2][Z_XR];  // two planes in flight: plane p is staged in v[p & 1] (loaded three planes ahead of its MFMAs)
     __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(abase), 0, 0, 0x00020000);
-    auto set_in_plane = [&](int j) {  // descriptor of input plane zin(j) (uniform)
-        rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(abase + (size_t)zin(j) * iplane), 0, (int)iplane32, 0x00020000);
+    auto set_in_plane = [&](int j) {  // descriptor of input plane zin(j) (uniform); zero records = a plane of zeros
+        rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(abase + (size_t)max(zin(j), 0) * iplane), 0,
+                                                live(j) ? (int)iplane32 : 0, 0x00020000);
     };
-    auto stage_load = [&](int u) { v[u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)rel[u], 0, 0); };
-    auto stage_write = [&](unsigned imgoff, int u) {
-        if (u < Z_XR - 1 || tid < Z_PARTS - (Z_XR - 1) * 256) *(lds_u4 *)(wa[u] + imgoff) = v[u];
+    auto stage_load = [&](int set, int u) { v[set][u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)rel[u], 0, 0); };
+    auto stage_write = [&](int set, unsigned imgoff, int u) {
+        if (u < Z_XR - 1 || tid < Z_PARTS - (Z_XR - 1) * 256) *(lds_u4 *)(wa[u] + imgoff) = v[set][u];
     };
-    auto load_plane = [&](int j) {
+    auto load_plane = [&](int set, int j) {
         set_in_plane(j);
 #pragma unroll
-        for (int u = 0; u < Z_XR; u++) stage_load(u);
+        for (int u = 0; u < Z_XR; u++) stage_load(set, u);
     };
-    auto store_plane = [&](unsigned imgoff) {
+    auto store_plane = [&](int set, unsigned imgoff) {
 #pragma unroll
-        for (int u = 0; u < Z_XR; u++) stage_write(imgoff, u);
+        for (int u = 0; u < Z_XR; u++) stage_write(set, imgoff, u);
     };
     i32x4 af[3];  // ring of three A fragments, fetched two fragments ahead (also across planes)
     // fragment f = (r * 3 + dx) * 2 + ks of plane image IMG
@@ -1139,44 +1143,44 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
         acc[rg * 4 + 0] = __uint_as_float(q.x); acc[rg * 4 + 1] = __uint_as_float(q.y);
         acc[rg * 4 + 2] = __uint_as_float(q.z); acc[rg * 4 + 3] = __uint_as_float(q.w);
     };
-    if (live(0)) {
-        load_plane(0);
-        store_plane(0);
-    }
-    if (live(1)) load_plane(1);
+    load_plane(0, 0);
+    store_plane(0, 0);
+    load_plane(1, 1);
+    load_plane(0, 2);
 #pragma unroll
     for (int p = 0; p < 27; p++) asm volatile("" : "+a"(bw[p][0]), "+a"(bw[p][1]));
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 32; q++) bias_init(S[q >> 3][(q >> 2) & 1], q & 3);
-    if (live(0)) {
-        MVD_Z_READ_A(0, 0, 0);
-        MVD_Z_READ_A(0, 1, 1);
-    }
+    MVD_Z_READ_A(0, 0, 0);
+    MVD_Z_READ_A(0, 1, 1);
 
     // plane j with ring position R = j & 3: input image R, accumulator sets NEW = R (output plane z'+1: first
     // contribution, holds the bias), MID = R-1 (z'), OLD = R-2 (z'-1: complete after this plane), DRAIN = R-3 (z'-2:
     // completed by the previous plane, stored during this one, then reset to the bias: it is the next plane's NEW).
-    // STEADY planes (all but the first four and the last few of a chunk): this plane, the next two and the drained output
-    // plane all exist -- no flags, no branches; the few scalar instructions a plane needs (two descriptors) sit in fragment
-    // slots.  Ablation (MVD_FWD16Z_DBG=61: MFMAs only) had shown 38.7 cycles per MFMA against 32.4 for the bare loop: ~60
-    // scalar instructions and five branches evaluating plane flags in one clump at every plane boundary -- an in-order wave
-    // issues no MFMA behind them.
-    auto plane = [&](auto Rc, auto Sc, int j) __attribute__((always_inline)) {
+    // ONE branch-free body for every plane: a plane that does not exist (z' = -1 or D at the volume faces, and the
+    // drain-only plane after the chunk) is a plane of zeros -- its descriptor has zero records, so the staging loads
+    // return zeros without touching memory -- and an output plane that is not the chunk's is a descriptor with zero
+    // records, so its stores are dropped.  Ablation (MVD_FWD16Z_DBG=61: MFMAs only) had shown 38.7 cycles per MFMA
+    // against 32.4 for the bare loop: ~60 scalar instructions and five branches evaluating plane flags in one clump at
+    // every plane boundary, and an in-order wave issues no MFMA behind them (a second, flag-free copy of the body for
+    // the interior planes made the register allocator spill 160 registers).  The price: 3 of the Zc + 3 planes of a chunk
+    // carry partly or wholly useless MFMAs.
+    auto plane = [&](auto Rc, int j) __attribute__((always_inline)) {
         constexpr int R = decltype(Rc)::value;
-        constexpr bool STEADY = decltype(Sc)::value != 0;
         constexpr int NEW = R, MID = (R + 3) & 3, OLD = (R + 2) & 3, DRN = (R + 1) & 3, RN = (R + 1) & 3;
-        const bool cur = STEADY || live(j), nxt = STEADY || live(j + 1), nxt2 = STEADY || live(j + 2);
-        const int zo = zin(j) - 2;  // the plane held by DRN
-        const bool st = (STEADY || (zo >= zb && zo < ze)) && !(dbg & 4);
-        // descriptor of the output plane; zero records when this set is not an output plane of the chunk: the four stores
-        // are then dropped by the range check (no branch)
-        __amdgpu_buffer_rsrc_t rout;
-        auto set_out_plane = [&]() {
-            rout = __builtin_amdgcn_make_buffer_rsrc(ybase + (size_t)(STEADY ? zo : max(zo, 0)) * oplane, 0,
-                                                     st ? (int)oplane32 : 0, 0x00020000);
+        __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, 0, 0x00020000);
+        auto set_out_plane = [&]() {  // the plane held by DRN
+            const int zo = zin(j) - 2;
+            const bool st = zo >= zb && zo < ze && !(dbg & 4);
+            rout = __builtin_amdgcn_make_buffer_rsrc(ybase + (size_t)max(zo, 0) * oplane, 0, st ? (int)oplane32 : 0, 0x00020000);
         };
-        if (!STEADY) set_out_plane();
+        auto set_next_in_plane = [&]() {  // input plane j + 3
+            const int z2 = zin(j + 3);
+            const bool lv = j + 3 < nproc && z2 >= 0 && z2 < g.Di && !(dbg & 1);
+            rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(abase + (size_t)max(z2, 0) * iplane), 0,
+                                                    lv ? (int)iplane32 : 0, 0x00020000);
+        };
         auto epi_pack = [&](int m, int rg) {  // 2 conversions + 1 ds_write_b64
             u32x2 q;
             q.x = cvt_pk_bf16(S[DRN][m][rg * 4 + 0], S[DRN][m][rg * 4 + 1]);
@@ -1187,84 +1191,69 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
         auto epi_read = [&](int q) { ob = *(lds_u4 *)(rsc + q * 1024); };
         auto epi_store = [&](int q) { __builtin_amdgcn_raw_buffer_store_b128(ob, rout, (int)voff[q], 0, 0); };
         constexpr unsigned IMGN = RN * Z_PLANE;
-        const bool do_w = nxt && !(dbg & 1), do_l = nxt2 && !(dbg & 1);
-        if (!STEADY && do_l) set_in_plane(j + 2);
-        if (cur) {
-            // everything that is not an MFMA is dealt out over the 24 fragment slots of the plane (an MFMA leaves ~24 issue
-            // cycles per 32; a clump in front of the plane is paid in full):
-            //   f 0-5   one staging ds_write_b128 (plane j+1, loaded during plane j-1) each
-            //   f 1-4   epilogue of the drained set: 4 conversions + 2 ds_write_b64 each
-            //   f 6-11  one global load (plane j+2) each;   f 6-13 scratch read-back and one 1-KB output store, alternating
-            //   f 14-21 one ds_read_b128 of the bias table into the drained set each
-            //   f 18    barrier (plane j+1 visible);        f 22-23 first fragments of plane j+1
+        // everything that is not an MFMA is dealt out over the 24 fragment slots of the plane (an MFMA leaves ~24 issue
+        // cycles per 32; a clump in front of the plane is paid in full):
+        //   f 1-14  one staging ds_write_b128 (plane j+1, loaded during plane j-2) in six of them
+        //   f 1-4   epilogue of the drained set: 4 conversions + 2 ds_write_b64 each;  f 0, 4 the two descriptors
+        //   f 3-23  one global load (plane j+3, into the registers just written out) in every fourth
+        //   f 6-13  scratch read-back and one 1-KB output store, alternating
+        //   f 14-21 one ds_read_b128 of the bias table into the drained set each
+        //   f 17-20 barrier (plane j+1 visible), wave w in slot 17 + w;   f 22-23 first fragments of plane j+1
 #pragma unroll
-            for (int f = 0; f < 24; f++) {
-                if (dbg & 32) {
-                } else if (f + 2 < 24) MVD_Z_READ_A(R, f + 2, (f + 2) % 3)
-                else if (nxt) MVD_Z_READ_A(RN, f + 2 - 24, (f + 2) % 3)  // behind the barrier below
-                if (f < 6 && do_w) stage_write(IMGN, f);
-                if (STEADY && f == 4) set_out_plane();
-                if (STEADY && f == 5 && do_l) set_in_plane(j + 2);
-                if (f == 1) asm volatile("" : "+v"(S[DRN][0]), "+v"(S[DRN][1]));  // keeps the conversions in their slots
-                if (f >= 1 && f <= 4 && !(dbg & 8)) {
-                    epi_pack((f - 1) >> 1, ((f - 1) & 1) * 2);
-                    epi_pack((f - 1) >> 1, ((f - 1) & 1) * 2 + 1);
-                }
-                if (f >= 6 && f < 12 && do_l) stage_load(f - 6);
-                if (f >= 6 && f < 14 && !(f & 1) && !(dbg & 8)) epi_read((f - 6) >> 1);
-                if (f >= 6 && f < 14 && (f & 1) && !(dbg & 8)) epi_store((f - 7) >> 1);
-                if (f >= 14 && f < 22) bias_init(S[DRN][(f - 14) >> 2], (f - 14) & 3);  // the next plane's NEW set
-                if (f == 18 && !(dbg & 16)) asm volatile("s_barrier" ::: "memory");  // this wave's plane writes retired in
-                                                                                       // order before the reads consumed above
-                const int r = f / 6, dx = (f >> 1) % 3, ks = f & 1;
+        for (int f = 0; f < 24; f++) {
+            if (dbg & 32) {
+            } else if (f + 2 < 24) MVD_Z_READ_A(R, f + 2, (f + 2) % 3)
+            else MVD_Z_READ_A(RN, f + 2 - 24, (f + 2) % 3)  // behind the barrier below
+            // The four waves run the same instruction stream, and one barrier per plane would keep them in lockstep: 24
+            // staging loads (and 24 13-cycle LDS store transfers) in one window of the CU's single vector-memory pipe.
+            // So wave w takes its barrier one fragment slot later than wave w-1 (slots 17 + w: behind its own last staging
+            // write, ahead of its first read of the next image) -- after the first plane the waves run w slots apart --
+            // and the staging loads sit in slots = 3 mod 4, the writes in slots = 1, 2 mod 4: no two waves load in the
+            // same slot time, and the compiler can still count vmcnt (conditional loads cost it the count).
+            if (!(dbg & 1)) {
+                constexpr int wslot[6] = {1, 2, 6, 9, 10, 14};
 #pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    const int dy = r - m;  // input row r is output row m shifted by dy - 1
-                    if (dy < 0 || dy > 2) continue;
-                    if (dbg & 2) continue;
-                    MVD_MFMA16_ZV(S[NEW][m], bw[0 * 9 + dy * 3 + dx][ks], af[f % 3]);
-                    MVD_MFMA16_ZV(S[MID][m], bw[1 * 9 + dy * 3 + dx][ks], af[f % 3]);
-                    MVD_MFMA16_ZV(S[OLD][m], bw[2 * 9 + dy * 3 + dx][ks], af[f % 3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < 6; u++)
+                    if (f == wslot[u]) stage_write(RN & 1, IMGN, u);
             }
-            // an MFMA result needs 12 wait states before anything but an accumulating MFMA reads it
-            asm volatile("s_nop 7\n\ts_nop 4" : "+v"(S[OLD][0]), "+v"(S[OLD][1]));
-        } else {
-            if (do_w) store_plane(IMGN);
-            if (do_l) {
-#pragma unroll
-                for (int u = 0; u < Z_XR; u++) stage_load(u);
+            if (f == 4 && !(dbg & 64)) set_out_plane();
+            if (f == 0 && !(dbg & 64)) set_next_in_plane();
+            if (f == 1) asm volatile("" : "+v"(S[DRN][0]), "+v"(S[DRN][1]));  // keeps the conversions in their slots
+            if (f >= 1 && f <= 4 && !(dbg & 8)) {
+                epi_pack((f - 1) >> 1, ((f - 1) & 1) * 2);
+                epi_pack((f - 1) >> 1, ((f - 1) & 1) * 2 + 1);
             }
-#pragma unroll
-            for (int q = 0; q < 8; q++) epi_pack(q >> 2, q & 3);
-#pragma unroll
-            for (int q = 0; q < 4; q++) { epi_read(q); epi_store(q); }
-#pragma unroll
-            for (int q = 0; q < 8; q++) bias_init(S[DRN][q >> 2], q & 3);
-            __syncthreads();
-            if (nxt) {
-                MVD_Z_READ_A(RN, 0, 0);
-                MVD_Z_READ_A(RN, 1, 1);
+            if ((f & 3) == 3 && !(dbg & 128)) stage_load(RN & 1, f >> 2);
+            if (f >= 6 && f < 14 && !(f & 1) && !(dbg & 8)) epi_read((f - 6) >> 1);
+            if (f >= 6 && f < 14 && (f & 1) && !(dbg & (8 | 128))) epi_store((f - 7) >> 1);
+            if (f >= 14 && f < 22 && !(dbg & 256)) bias_init(S[DRN][(f - 14) >> 2], (f - 14) & 3);  // the next plane's NEW set
+            if (f >= 17 && f <= 20 && !(dbg & 16)) {
+                // (this wave's plane writes retired in order before the fragment reads already consumed above)
+                if (wave == f - 17) asm volatile("s_barrier" ::: "memory");
             }
+            const int r = f / 6, dx = (f >> 1) % 3, ks = f & 1;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const int dy = r - m;  // input row r is output row m shifted by dy - 1
+                if (dy < 0 || dy > 2) continue;
+                if (dbg & 2) continue;
+                MVD_MFMA16_ZV(S[NEW][m], bw[0 * 9 + dy * 3 + dx][ks], af[f % 3]);
+                MVD_MFMA16_ZV(S[MID][m], bw[1 * 9 + dy * 3 + dx][ks], af[f % 3]);
+                MVD_MFMA16_ZV(S[OLD][m], bw[2 * 9 + dy * 3 + dx][ks], af[f % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // an MFMA result needs 12 wait states before anything but an accumulating MFMA reads it
+        asm volatile("s_nop 7\n\ts_nop 4" : "+v"(S[OLD][0]), "+v"(S[OLD][1]));
     };
-    const int jhi = min(nproc, g.Di - zb + 1);  // live(j) <=> jlo <= j < jhi with jlo <= 1
-    for (int j = 0; j <= nproc; j += 4) {
-        if (j >= 4 && j + 5 < jhi) {  // planes j .. j+3 are steady (j+3+2 is live; their drained planes belong to the chunk)
-            plane(ZIdx<0>(), ZIdx<1>(), j);
-            plane(ZIdx<1>(), ZIdx<1>(), j + 1);
-            plane(ZIdx<2>(), ZIdx<1>(), j + 2);
-            plane(ZIdx<3>(), ZIdx<1>(), j + 3);
-            continue;
-        }
-        plane(ZIdx<0>(), ZIdx<0>(), j);
+    for (int j = 0; j <= ((dbg & 512) ? -1 : nproc); j += 4) {
+        plane(ZIdx<0>(), j);
         if (j + 1 > nproc) break;
-        plane(ZIdx<1>(), ZIdx<0>(), j + 1);
+        plane(ZIdx<1>(), j + 1);
         if (j + 2 > nproc) break;
-        plane(ZIdx<2>(), ZIdx<0>(), j + 2);
+        plane(ZIdx<2>(), j + 2);
         if (j + 3 > nproc) break;
-        plane(ZIdx<3>(), ZIdx<0>(), j + 3);
+        plane(ZIdx<3>(), j + 3);
     }
 #undef MVD_Z_READ_A
 }
@@ -1326,7 +1315,7 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
         }
         // measured (round 2, enc0.conv1 dgrad, bench_conv --iters 40): k_fwd16r 0.282 ms, k_fwd16q 0.258 ms -- the DMA
         // pieces cost the wave more issue time than ten register loads + ten ds_write_b128.  Selectable, off by default.
-        static const int use_z = getenv("MVD_FWD16Z") ? atoi(getenv("MVD_FWD16Z")) : 0;
+        static const int use_z = getenv("MVD_FWD16Z") ? atoi(getenv("MVD_FWD16Z")) : 1;  // default (round 2): k_fwd16z
         if (ok && use_z) {
             Fwd16ZTile tz;
             memset(&tz, 0, sizeof(tz));
@@ -1347,7 +1336,7 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
             tz.zc = (g.Do + best - 1) / best;
             tz.nzc = (g.Do + tz.zc - 1) / tz.zc;
             tz.nitems = (int)(cols * tz.nzc);
-            static const int dbgz = getenv("MVD_FWD16Z_DBG") ? atoi(getenv("MVD_FWD16Z_DBG")) & 63 : 0;
+            static const int dbgz = getenv("MVD_FWD16Z_DBG") ? atoi(getenv("MVD_FWD16Z_DBG")) & 1023 : 0;
             typedef void (*kz_t)(const FwdGeom, const Fwd16ZTile, const unsigned short *, const unsigned short *, const float *,
                                  unsigned short *);
             kz_t kfn = k_fwd16z<0>;
@@ -1359,8 +1348,11 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
                 case 13: kfn = k_fwd16z<13>; break;
                 case 29: kfn = k_fwd16z<29>; break;
                 case 61: kfn = k_fwd16z<61>; break;
-                case 21: kfn = k_fwd16z<21>; break;
-                case 37: kfn = k_fwd16z<37>; break;
+                case 125: kfn = k_fwd16z<125>; break;
+                case 189: kfn = k_fwd16z<189>; break;
+                case 317: kfn = k_fwd16z<317>; break;
+                case 509: kfn = k_fwd16z<509>; break;
+                case 1021: kfn = k_fwd16z<1021>; break;
                 default: break;
             }
             static bool configured_z = false;
