@@ -103,7 +103,7 @@ def bf16_block_roofline(torch, dev, patch):
     flops = 2.0 * 27 * C * K * V
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     roof = {"kernel": f"conv3d_fwd 32->32 @{'x'.join(map(str, patch))} bf16 (fwd-type implicit GEMM on "
-                      "v_mfma_f32_32x32x16_bf16, persistent, weights resident in accumulator registers: k_fwd16q)",
+                      "v_mfma_f32_32x32x16_bf16, z-marching 8x32 columns, weights resident in accumulator registers: k_fwd16z)",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_GB_per_launch": round(alg_bytes / 1e9, 4),
             "traffic": measured_traffic("traffic_bytes_per_launch_bf16"), "ms_per_launch": round(ms, 4),

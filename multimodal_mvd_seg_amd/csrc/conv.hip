@@ -345,9 +345,9 @@ static int run_fwd16(const FwdGeom &g, const uint16_t *a1, const uint16_t *a2, c
 }
 
 static int run_wgrad16(const WgradGeom &g, const uint16_t *a1, const uint16_t *a2, const uint16_t *b, float *dw, void *ws,
-                       size_t ws_bytes, hipStream_t s) {
+                       size_t ws_bytes, hipStream_t s, float *dbias = nullptr, int *dbias_done = nullptr) {
     int r = wgrad_mfma(g, reinterpret_cast<const float *>(a1), reinterpret_cast<const float *>(a2),
-                       reinterpret_cast<const float *>(b), dw, ws, ws_bytes, s, true);
+                       reinterpret_cast<const float *>(b), dw, ws, ws_bytes, s, true, dbias, dbias_done);
     if (r < 0) {
         set_error("bf16 wgrad: unsupported shape (needs C %% 32 == 0 and K %% 32 == 0; C=%d+%d K=%d)", g.C1, g.C2, g.K);
         return 3;
@@ -843,11 +843,12 @@ int mvd_conv3d_wgrad_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2
     MVD_REQUIRE(ws_bytes >= mvd_conv3d_wgrad_workspace_bytes(C1 + C2, K, g.T, N, g.Do, g.Ho, g.Wo),
                 "conv3d_wgrad_bf16: workspace too small");
     hipStream_t s = as_stream(stream);
-    if (dbias) {
-        int r = colsum(reinterpret_cast<const float *>(dy), dbias, (long)N * g.Do * g.Ho * g.Wo, K, ws, s, true);
-        if (r) return r;
-    }
-    return run_wgrad16(g, x1, x2, dy, dw, ws, ws_bytes, s);
+    // the 27-tap kernel produces the bias gradient from its idle tap slot; the other shapes take the column-sum pass
+    int dbias_done = 0;
+    int r = run_wgrad16(g, x1, x2, dy, dw, ws, ws_bytes, s, dbias, &dbias_done);
+    if (r) return r;
+    if (dbias && !dbias_done) return colsum(reinterpret_cast<const float *>(dy), dbias, (long)N * g.Do * g.Ho * g.Wo, K, ws, s, true);
+    return 0;
 }
 
 int mvd_convT3d_wgrad_bf16(const uint16_t *x, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W, int C, int K,

@@ -2062,7 +2062,8 @@ template <int TPW, int NA, int NB, int SH>
 __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgTile tg,
                                                     const unsigned short *__restrict__ a1,
                                                     const unsigned short *__restrict__ a2,
-                                                    const unsigned short *__restrict__ b, float *__restrict__ partial) {
+                                                    const unsigned short *__restrict__ b, float *__restrict__ partial,
+                                                    float *__restrict__ pbias) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     unsigned char *As = lds8;
     unsigned char *Bs = lds8 + (size_t)NA * 4096;
@@ -2210,6 +2211,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
         steptab[e] = make_int4(t4[0], t4[1], t4[2], t4[3]);
     }
 
+    // Bias gradient (SH == 1: every tap reads the same dy fragment): with 27 taps over 4 waves x 7 slots the last slot of
+    // wave 3 is idle -- its A operand becomes a block of ones, so its accumulator rows are the column sums of dy over
+    // the voxels of this workgroup's tiles (fp32 accumulation of bf16 values, like the weight gradient itself).  Replaces
+    // a separate pass over dy (k_colsum4) per layer.
+    const bool ones_slot = SH == 1 && pbias != nullptr && wave + 4 * (TPW - 1) >= g.ntaps;
+    bf16x8w ones;
+#pragma unroll
+    for (int e = 0; e < 8; e++) ones[e] = (__bf16)1.0f;
+
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
     while (tile < tg.ntiles) {
@@ -2223,7 +2233,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
             const int sa_[2] = {t4.x, t4.y}, sb_[2] = {t4.z, t4.w};
             bf16x8w av[NAV], bv[NBV];
 #pragma unroll
-            for (int j = 0; j < NAV; j++) av[j] = tr_operand(As + sa_[0] + aoff[j], As + sa_[1] + aoff[j]);
+            for (int j = 0; j < NAV; j++) {
+                if (SH == 1 && j == TPW - 1 && ones_slot) av[j] = ones;  // wave-uniform
+                else av[j] = tr_operand(As + sa_[0] + aoff[j], As + sa_[1] + aoff[j]);
+            }
 #pragma unroll
             for (int j = 0; j < NBV; j++) bv[j] = tr_operand(Bs + sb_[0] + boff[j], Bs + sb_[1] + boff[j]);
 #pragma unroll
@@ -2244,6 +2257,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
             }
         }
     }
+    // every row of the ones-slot accumulator holds the same sums: row 0 (lane half 0, register 0) of the c-block-0
+    // workgroups goes out, one row per split
+    if (ones_slot && cb == 0 && h == 0) pbias[(size_t)split * K + k0 + i] = acc[TPW - 1][0];
 }
 
 // dw[torch layout] = sum_split partial[split][t][c][k]   (fp32 partials, fp64 sum, fixed order).
@@ -2419,8 +2435,14 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         const unsigned short *h1 = reinterpret_cast<const unsigned short *>(a1);
         const unsigned short *h2 = reinterpret_cast<const unsigned short *>(a2);
         const unsigned short *hb = reinterpret_cast<const unsigned short *>(b);
-#define WG16(TPW, NA, NB, SH) \
-    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096 + 8192, s, g, tg, h1, h2, hb, partial)
+        // bias gradient from the idle 28th tap slot (k_wgrad16): 27 taps, 7 slots per wave, one dy fragment for all taps
+        float *pbias16 = nullptr;
+        if (dbias && dbias_done && cfg == 0 && sameB && tpw == 7 && g.ntaps < 28 &&
+            need_ws + (size_t)tg.nsplit * g.K * sizeof(float) <= ws_bytes)
+            pbias16 = partial + need_ws / sizeof(float);
+#define WG16(TPW, NA, NB, SH)                                                                                              \
+    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096 + 8192, s, g, tg, h1, h2, hb, \
+                       partial, (TPW) == 7 && (SH) == 1 ? pbias16 : nullptr)
 #define WG16_TPW(NA, NB, SH)                  \
     {                                         \
         if (tpw <= 1) WG16(1, NA, NB, SH);    \
@@ -2438,6 +2460,11 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
 #undef WG16_TPW
 #undef WG16
         if (check_launch("conv wgrad (bf16 mfma)")) return 1;
+        if (pbias16) {
+            hipLaunchKernelGGL(k_dbias_reduce, dim3(cdiv(g.K, 64)), dim3(1024), 0, s, pbias16, dbias, g.K, tg.nsplit);
+            if (check_launch("conv wgrad dbias reduce (bf16)")) return 1;
+            *dbias_done = 1;
+        }
         const long per16 = (long)g.ntaps * C * g.K;
         hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per16, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit);
         return check_launch("conv wgrad reduce (bf16 mfma)");

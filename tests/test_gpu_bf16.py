@@ -81,6 +81,31 @@ def test_conv3d_bf16_fwd_dgrad(C1, C2, K, sp, stride, N):
         close_bf16(dx2, xs[1].grad, "dx2")
 
 
+@pytest.mark.parametrize("N,D,H,W", [(2, 52, 60, 44), (2, 33, 70, 97), (3, 17, 41, 130), (1, 128, 64, 64)])
+def test_conv3d_bf16_zmarch_ragged_shapes_exact(N, D, H, W):
+    """k_fwd16z (32 -> 32 channels, the z-marching kernel of the headline bf16 block) on volumes whose extents are not
+    multiples of its 8 x 32 column, with z chunks that end inside and at the volume faces, forward and input gradient,
+    on small-integer data: every product and fp32 partial sum is an exact integer, so the result must equal torch's
+    exact fp32 convolution rounded once to bf16, bit for bit (halo zero-fill through the descriptor range check, dropped
+    out-of-volume stores, the accumulator ring and the bias re-initialisation all show up as wrong integers)."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(D * 7 + H)
+    ints = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=g).float()
+    x, w, b = ints((N, 32, D, H, W), -2, 2), ints((32, 32, 3, 3, 3), -2, 2), ints((32,), -3, 3)
+    xr = x.clone().requires_grad_()
+    ref = F.conv3d(xr, w, b, 1, 1)
+    gy = ints(tuple(ref.shape), -1, 1)
+    ref.backward(gy)
+    cl, BF = torch.channels_last_3d, torch.bfloat16
+    gx = x.to(DEV).to(BF).contiguous(memory_format=cl).requires_grad_()
+    gw, gb = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.Conv3dFn.apply(gx, None, gw, gb, (1, 1, 1))
+    y.backward(gy.to(DEV).to(BF).contiguous(memory_format=cl))
+    assert torch.equal(y.detach().cpu(), ref.detach().to(BF)), "y"
+    assert torch.equal(gx.grad.cpu(), xr.grad.to(BF)), "dx"
+
+
+
 @pytest.mark.parametrize("C,K,sp,N", [(64, 32, (4, 5, 6), 2), (320, 256, (2, 2, 2), 2)])
 def test_convT3d_bf16_fwd_dgrad(C, K, sp, N):
     from multimodal_mvd_seg_amd._lib import call, i3, query
