@@ -121,6 +121,10 @@ int mvd_convT3d_wgrad(const float *x, const float *dy, float *dw, float *dbias, 
  * mvd_pack_weight_bf16: torch fp32 weight -> wf16 (reduce C, produce K) / wb16 (reduce K, produce C), layout
  * [chunk32][tap][kstep][lane half][out channel][8]. */
 int mvd_pack_weight_bf16(const float *w, uint16_t *wf, uint16_t *wb, int K, int C, int T, int transposed, void *stream);
+/* Every bf16 pack of a network in ONE launch (called by the fused optimizer after its update, like
+ * mvd_pack_weights_batch for the fp32 layouts): host tables of n jobs, outputs bit-identical to mvd_pack_weight_bf16. */
+int mvd_pack_weights_bf16_batch(int n, const float *const *w, uint16_t *const *wf, uint16_t *const *wb, const int *K,
+                                const int *C, const int *T, const int *transposed, void *stream);
 int mvd_conv3d_fwd_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *wf, const float *bias,
                         uint16_t *y, int N, int D, int H, int W, int K, const int ksize[3], const int stride[3],
                         void *ws, size_t ws_bytes, void *stream);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mvd_cast_f32_to_bf16": (c_int, [_P, _P, c_long, _P]),
     "mvd_cast_bf16_to_f32": (c_int, [_P, _P, c_long, _P]),
     "mvd_pack_weight_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "mvd_pack_weights_bf16_batch": (c_int, [c_int] + [_P] * 7 + [_P]),
     "mvd_conv3d_fwd_bf16": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                     c_size_t, _P]),
     "mvd_conv3d_dgrad_bf16": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,

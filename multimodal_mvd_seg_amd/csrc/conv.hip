@@ -699,6 +699,19 @@ int mvd_pack_weight_bf16(const float *w, uint16_t *wf, uint16_t *wb, int K, int 
     return pack_weight16(w, wf, wb, K, C, T, transposed, as_stream(stream));
 }
 
+int mvd_pack_weights_bf16_batch(int n, const float *const *w, uint16_t *const *wf, uint16_t *const *wb, const int *K,
+                                const int *C, const int *T, const int *transposed, void *stream) {
+    MVD_REQUIRE(n > 0 && w && wf && wb && K && C && T && transposed, "pack_weights_bf16_batch: null table");
+    for (int q = 0; q < n; q++) {
+        MVD_REQUIRE(w[q] && (wf[q] || wb[q]), "pack_weights_bf16_batch: job without source or destination");
+        MVD_REQUIRE(K[q] > 0 && C[q] > 0 && T[q] > 0 && T[q] <= MVD_MAX_TAPS, "pack_weights_bf16_batch: bad K / C / T");
+        MVD_REQUIRE(!wf[q] || C[q] % 32 == 0, "pack_weights_bf16_batch: wf needs C %% 32 == 0");
+        MVD_REQUIRE(!wb[q] || K[q] % 32 == 0, "pack_weights_bf16_batch: wb needs K %% 32 == 0");
+    }
+    return pack_weights16_batch(n, w, reinterpret_cast<unsigned short *const *>(wf), reinterpret_cast<unsigned short *const *>(wb),
+                                K, C, T, transposed, as_stream(stream));
+}
+
 int mvd_conv3d_fwd_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *wf, const float *bias, uint16_t *y, int N,
                    int D, int H, int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes,
                    void *stream) {

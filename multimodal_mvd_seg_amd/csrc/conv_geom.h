@@ -102,5 +102,7 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
              const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s);
 int pack_weight16(const float *w, unsigned short *wf, unsigned short *wb, int K, int C, int T, int transposed,
                   hipStream_t s);
+int pack_weights16_batch(int n, const float *const *w, unsigned short *const *wf, unsigned short *const *wb, const int *K,
+                         const int *C, const int *T, const int *transposed, hipStream_t s);
 
 }  // namespace mvd

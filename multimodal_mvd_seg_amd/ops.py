@@ -137,6 +137,7 @@ def pack_weight(weight, transposed):
 # such code must call invalidate_packs() (FlatParams.invalidate_packs).
 _PACK_EPOCH = [0]
 _PACK_LIVE = []
+_PACK16_LIVE = []
 
 
 def invalidate_packs():
@@ -216,9 +217,50 @@ def _packed(weight, transposed, want_uf=False, want_ub=False):
     return e
 
 
+def _repack_all_bf16():
+    """The bf16 packs of every live weight that has them, in one launch (mvd_pack_weights_bf16_batch) into views of ONE
+    fresh buffer per device: the tensors a graph saved for backward keep their old buffer alive, exactly as with the
+    per-layer packs (fresh tensors per stamp)."""
+    jobs, alive = [], []
+    for r in _PACK16_LIVE:
+        w = r()
+        e = getattr(w, "_mvd_pack16", None) if w is not None else None
+        if e is None:
+            continue
+        alive.append(r)
+        d = w.detach()
+        if d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.device == e[0][2]:
+            jobs.append((d, e[0][1], w))
+    _PACK16_LIVE[:] = alive
+    for dev in {d.device for d, _, _w in jobs}:
+        js = [j for j in jobs if j[0].device == dev]
+        sizes = [d.numel() for d, _, _w in js]
+        pad = lambda n: (n + 127) // 128 * 128  # 256-byte aligned views
+        buf = torch.empty((2 * sum(pad(n) for n in sizes),), dtype=BF16, device=dev)
+        views, o = [], 0
+        for n in sizes:
+            views.append((buf[o:o + n], buf[o + pad(n):o + pad(n) + n]))
+            o += 2 * pad(n)
+        n = len(js)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        shp = []
+        for (d, tr, _w) in js:
+            (C, K) = d.shape[:2] if tr else (d.shape[1], d.shape[0])
+            shp.append((K, C, d[0, 0].numel()))
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        with torch.cuda.device(dev):
+            call("mvd_pack_weights_bf16_batch", n, cast(PA(*[d.data_ptr() for d, _, _w in js])),
+                 cast(PA(*[v[0].data_ptr() for v in views])), cast(PA(*[v[1].data_ptr() for v in views])),
+                 cast(IA(*[q[0] for q in shp])), cast(IA(*[q[1] for q in shp])), cast(IA(*[q[2] for q in shp])),
+                 cast(IA(*[1 if tr else 0 for _, tr, _w in js])), _stream())
+        for (d, tr, w), v in zip(js, views):
+            w._mvd_pack16 = ((_pack_stamp(d, w), tr, d.device), v[0], v[1])
+
+
 def repack_all():
     """Called by the fused optimizer after its update: new epoch, every live cached weight re-packed in one launch."""
     _PACK_EPOCH[0] += 1
+    _repack_all_bf16()
     jobs, alive = [], []
     for r in _PACK_LIVE:
         w = r()
@@ -272,12 +314,17 @@ def pack_weight_bf16(weight, transposed):
 
 def _packed_bf16(weight, transposed):
     """bf16 packs cached on the weight tensor under the same (epoch, version) stamp as the fp32 ones: inference packs
-    once; in training the optimizer step makes them stale and the next forward re-packs them per layer."""
+    once; in training the fused optimizer re-packs every registered weight in one launch after its update
+    (repack_all -> mvd_pack_weights_bf16_batch); a stale or missing entry is packed here, per layer."""
     w = weight.detach()
     if not w.is_contiguous():
         return pack_weight_bf16(weight, transposed)
     e = getattr(weight, "_mvd_pack16", None)
     if e is None or e[0] != (_pack_stamp(w, weight), transposed, w.device):
+        if e is None:
+            if len(_PACK16_LIVE) >= 4096:
+                _PACK16_LIVE[:] = [r for r in _PACK16_LIVE if r() is not None]
+            _PACK16_LIVE.append(weakref.ref(weight))
         e = ((_pack_stamp(w, weight), transposed, w.device),) + tuple(pack_weight_bf16(weight, transposed))
         weight._mvd_pack16 = e
     return e[1], e[2]

@@ -106,6 +106,34 @@ def test_conv3d_bf16_zmarch_ragged_shapes_exact(N, D, H, W):
 
 
 
+def test_bf16_packs_follow_the_fused_optimizer_in_one_launch():
+    """After FusedSGDNesterov.step() (raw-pointer update of the flat buffer) every registered bf16 pack is rebuilt by ONE
+    batched launch (ops.repack_all -> mvd_pack_weights_bf16_batch) into fresh tensors: the cached entry must carry the
+    new stamp without a per-layer pack, equal the per-layer pack of the updated weight bit for bit (conv and transposed
+    conv layouts), and the tensors a graph saved before the step must be untouched."""
+    from multimodal_mvd_seg_amd import ops, optim
+    g = torch.Generator().manual_seed(5)
+    conv = torch.nn.Conv3d(32, 64, 3, padding=1).to(DEV)
+    convT = torch.nn.ConvTranspose3d(64, 32, 2, stride=2).to(DEV)
+    x = torch.randn(1, 32, 6, 6, 8, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    opt = optim.FusedSGDNesterov(list(conv.parameters()) + list(convT.parameters()), 0.1, weight_decay=0.0, momentum=0.9,
+                                 max_grad_norm=12)
+    y = ops.Conv3dFn.apply(x, None, conv.weight, conv.bias, (1, 1, 1))
+    z = ops.ConvTranspose3dFn.apply(y, convT.weight, convT.bias, (2, 2, 2))
+    old = conv.weight._mvd_pack16
+    old_wf = old[1].clone()
+    z.backward(torch.ones_like(z).contiguous(memory_format=torch.channels_last_3d))
+    opt.step()
+    for mod, tr in ((conv, False), (convT, True)):
+        e = mod.weight._mvd_pack16
+        assert e[0] == (ops._pack_stamp(mod.weight.detach(), mod.weight), tr, mod.weight.device)
+        wf, wb = ops.pack_weight_bf16(mod.weight, tr)
+        assert torch.equal(e[1], wf) and torch.equal(e[2], wb)
+    assert conv.weight._mvd_pack16[1].data_ptr() != old[1].data_ptr()
+    assert torch.equal(old[1], old_wf)  # the pre-step pack is still what the old graph saw
+    assert not torch.equal(conv.weight._mvd_pack16[1], old_wf)
+
+
 @pytest.mark.parametrize("C,K,sp,N", [(64, 32, (4, 5, 6), 2), (320, 256, (2, 2, 2), 2)])
 def test_convT3d_bf16_fwd_dgrad(C, K, sp, N):
     from multimodal_mvd_seg_amd._lib import call, i3, query
