@@ -117,7 +117,7 @@ int mvd_convT3d_wgrad(const float *x, const float *dy, float *dw, float *dbias, 
 /* ------------------------------------------------------------------------------------------------------------
  * bf16 mixed precision (BASELINE cfg 4/5: the reference's autocast path, nnUNetTrainer.py:906): activations and
  * packed weights are bf16 (uint16_t storage), accumulation and bias fp32, outputs bf16; master weights and all
- * weight gradients stay fp32.  C % 32 == 0 and K % 32 == 0 (the 4-modality input layer runs on the fp32 entry points).
+ * weight gradients stay fp32.  C % 32 == 0 and K % 32 == 0 (the 4-modality input layer: mvd_pad_channels_bf16 first).
  * mvd_pack_weight_bf16: torch fp32 weight -> wf16 (reduce C, produce K) / wb16 (reduce K, produce C), layout
  * [chunk32][tap][kstep][lane half][out channel][8]. */
 int mvd_pack_weight_bf16(const float *w, uint16_t *wf, uint16_t *wb, int K, int C, int T, int transposed, void *stream);
@@ -345,6 +345,10 @@ int mvd_sgd_nesterov_step(float *p, const float *g, float *buf, const float *sum
 /* misc elementwise helpers used by the host glue (all fixed-order / exact) */
 int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *stream);
 int mvd_ndhwc_to_nchw(const float *src, float *dst, int N, int C, long V, void *stream);
+/* bf16 mixed precision, narrow network input (4 modalities): fp32 [N][C][V] (src_ndhwc = 0) or [N][V][C] -> bf16
+ * [N][V][Cpad] with zero channels C .. Cpad-1 (C <= 8, Cpad = 32), so that the first conv runs on the 32-channel bf16
+ * engines (get_network_from_plans.py:41-44 under the autocast of nnUNetTrainer.py:906: bf16 operands, fp32 accumulate). */
+int mvd_pad_channels_bf16(const float *src, uint16_t *dst, int N, int C, int Cpad, long V, int src_ndhwc, void *stream);
 int mvd_axpy(float *y, const float *x, float a, long n, void *stream); /* y += a*x */
 
 /* ------------------------------------------------------------------------------------------------------------

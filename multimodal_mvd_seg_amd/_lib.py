@@ -118,6 +118,7 @@ SIGNATURES = {
     "mvd_grad_sumsq": (c_int, [_P, _P, c_long, _P, c_size_t, _P]),
     "mvd_sgd_nesterov_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "mvd_nchw_to_ndhwc": (c_int, [_P, _P, c_int, c_int, c_long, _P]),
+    "mvd_pad_channels_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_long, c_int, _P]),
     "mvd_ndhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_long, _P]),
     "mvd_axpy": (c_int, [_P, _P, c_float, c_long, _P]),
     "mvd_flip_add": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -58,6 +58,30 @@ __global__ void k_nchw_to_ndhwc_c4(const float *__restrict__ src, float *__restr
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x)
         *reinterpret_cast<float4 *>(dst + ((size_t)n * V + v) * 4) = make_float4(s[v], s[V + v], s[2 * V + v], s[3 * V + v]);
 }
+// fp32 [N][C][V] (planar) or [N][V][C] (ndhwc != 0), C <= 8 -> bf16 [N][V][Cpad] with zero channels C .. Cpad-1: four lanes per
+// voxel, lane part p writes the 16-byte piece p (a wave instruction stores 1 KB contiguous); only part 0 reads
+template <int CPAD>
+__global__ void k_pad_channels_bf16(const float *__restrict__ src, unsigned short *__restrict__ dst, int C, long V, int ndhwc) {
+    const int n = blockIdx.y;
+    constexpr int PARTS = CPAD / 8;
+    const long total = V * PARTS;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long v = i / PARTS;
+        const int part = (int)(i - v * PARTS);
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (part == 0) {
+            float f[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                f[c] = c < C ? (ndhwc ? src[((size_t)n * V + v) * C + c] : src[((size_t)n * C + c) * V + v]) : 0.f;
+            q.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+            q.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+            q.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+            q.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+        }
+        *reinterpret_cast<uint4 *>(dst + ((size_t)n * V + v) * CPAD + part * 8) = q;
+    }
+}
 __global__ void k_ndhwc_to_nchw(const float *__restrict__ src, float *__restrict__ dst, int C, long V) {
     __shared__ float tile[32][33];
     long v0 = (long)blockIdx.x * 32;
@@ -139,6 +163,16 @@ int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *
     dim3 g(cdiv(V, 32), cdiv(C, 32), N);
     hipLaunchKernelGGL(k_nchw_to_ndhwc, g, dim3(256), 0, as_stream(stream), src, dst, C, V);
     return check_launch("nchw_to_ndhwc");
+}
+int mvd_pad_channels_bf16(const float *src, uint16_t *dst, int N, int C, int Cpad, long V, int src_ndhwc, void *stream) {
+    MVD_REQUIRE(src && dst && N > 0 && N <= 65535 && V > 0, "pad_channels_bf16: bad arguments");
+    MVD_REQUIRE(C >= 1 && C <= 8 && Cpad == 32, "pad_channels_bf16: C must be 1..8 and Cpad 32");
+    MVD_REQUIRE((((uintptr_t)dst) & 15) == 0, "pad_channels_bf16: dst must be 16-byte aligned");
+    long bx = cdiv(V * 4, 256);
+    if (bx > 16384) bx = 16384;
+    hipLaunchKernelGGL(k_pad_channels_bf16<32>, dim3((unsigned)bx, N), dim3(256), 0, as_stream(stream), src,
+                       reinterpret_cast<unsigned short *>(dst), C, V, src_ndhwc);
+    return check_launch("pad_channels_bf16");
 }
 int mvd_ndhwc_to_nchw(const float *src, float *dst, int N, int C, long V, void *stream) {
     MVD_REQUIRE(src && dst && N > 0 && C > 0 && V > 0 && N <= 65535, "ndhwc_to_nchw: bad arguments");

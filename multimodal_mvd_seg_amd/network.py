@@ -87,7 +87,13 @@ class ConvDropoutNormReLU(nn.Module):
         self.precision = "fp32"  # "bf16": see set_precision()
 
     def forward(self, x, x2=None):
-        y = self.conv(x, x2)
+        cw = self.conv.weight
+        if (self.precision == "bf16" and x2 is None and x.dtype == torch.float32 and x.shape[1] <= 8 and
+                cw.shape[0] % 32 == 0 and tuple(cw.shape[2:]) == (3, 3, 3) and self.stride == (1, 1, 1) and x.is_cuda):
+            # the 4-modality input layer under mixed precision: bf16 operands like every other conv of the net
+            y = ops.NarrowInputConv3dBf16Fn.apply(x, cw, self.conv.bias)
+        else:
+            y = self.conv(x, x2)
         return ops.InstanceNormLeakyReLUFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps,
                                                  self.nonlin.negative_slope,
                                                  self.precision == "bf16")
@@ -279,10 +285,11 @@ class MI355PlainConvUNet(nn.Module):
 
 def set_precision(module: nn.Module, precision: str):
     """Mixed precision of the reference's autocast path (nnUNetTrainer.py:906; BASELINE cfg 4/5), MI355X style:
-    "bf16" makes every fused InstanceNorm+LeakyReLU emit bf16, so every conv / transposed conv / seg head after the
-    first one reads bf16 activations and runs on the bf16 MFMA engine (fp32 accumulate).  Parameters, the 4-modality
-    input conv, normalisation statistics, logits, losses, weight gradients and the optimizer stay fp32 -- bf16 has
-    fp32's exponent range, so there is no GradScaler (the reference needs one for fp16, nnUNetTrainer.py:916-920)."""
+    "bf16" makes every fused InstanceNorm+LeakyReLU emit bf16, so every conv / transposed conv / seg head reads bf16
+    activations and runs on the bf16 MFMA engine (fp32 accumulate); the 4-modality input conv converts its fp32 input to
+    bf16 itself (ops.NarrowInputConv3dBf16Fn: channels zero-padded to 32), as autocast does.  Parameters, normalisation
+    statistics, logits, losses, weight gradients and the optimizer stay fp32 -- bf16 has fp32's exponent range, so there
+    is no GradScaler (the reference needs one for fp16, nnUNetTrainer.py:916-920)."""
     if precision not in ("fp32", "bf16"):
         raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
     for m in module.modules():

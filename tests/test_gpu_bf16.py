@@ -106,6 +106,32 @@ def test_conv3d_bf16_zmarch_ragged_shapes_exact(N, D, H, W):
 
 
 
+@pytest.mark.parametrize("N,C,sp,planar", [(2, 4, (12, 10, 14), True), (1, 4, (33, 70, 97), True), (2, 1, (9, 8, 40), False)])
+def test_narrow_input_conv_bf16_exact_integer_data(N, C, sp, planar):
+    """The 4-modality input conv under bf16 mixed precision (ops.NarrowInputConv3dBf16Fn: channels zero-padded to 32, bf16
+    MFMA engines) on small-integer data: operands exact in bf16, every fp32 partial sum an exact integer -> y must be
+    torch's exact fp32 conv rounded once to bf16, the weight / bias gradients (fp32) exact, bit for bit.  Covers the pad
+    kernel for planar and NDHWC sources, the padded weight pack, the dropped gradient of the zero channels, and (second
+    case) the z-marching kernel fed by the padded tensor."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(11 * C + sp[0])
+    ints = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=g).float()
+    x, w, b = ints((N, C, *sp), -2, 2), ints((32, C, 3, 3, 3), -2, 2), ints((32,), -3, 3)
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.conv3d(x, wr, br, 1, 1)
+    gy = ints(tuple(ref.shape), -1, 1)
+    ref.backward(gy)
+    gx = x.to(DEV) if planar else x.to(DEV).contiguous(memory_format=torch.channels_last_3d)
+    gw, gb = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = ops.NarrowInputConv3dBf16Fn.apply(gx, gw, gb)
+    assert y.dtype == torch.bfloat16
+    y.backward(gy.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d))
+    assert torch.equal(y.detach().cpu(), ref.detach().to(torch.bfloat16)), "y"
+    assert gw.grad.dtype == torch.float32 and tuple(gw.grad.shape) == tuple(w.shape)
+    assert torch.equal(gw.grad.cpu(), wr.grad), f"dw (max {float((gw.grad.cpu() - wr.grad).abs().max())})"
+    assert torch.equal(gb.grad.cpu(), br.grad), "db"
+
+
 def test_bf16_packs_follow_the_fused_optimizer_in_one_launch():
     """After FusedSGDNesterov.step() (raw-pointer update of the flat buffer) every registered bf16 pack is rebuilt by ONE
     batched launch (ops.repack_all -> mvd_pack_weights_bf16_batch) into fresh tensors: the cached entry must carry the
