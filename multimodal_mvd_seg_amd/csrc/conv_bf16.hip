@@ -978,6 +978,7 @@ static_assert(Z_PLANE + Z_HALF < 65536, "plane / k-step offsets must fit the 16-
 
 struct Fwd16ZTile {
     int nty, ntx, nzc, zc, nitems;
+    int kp, koff;  // produce channels of the packed weight tensor (its row stride), first produce channel of this launch
     int wsel[27];
 };
 
@@ -1030,7 +1031,8 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
     for (int p = 0; p < 27; p++)
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(w + ((size_t)tg.wsel[p] * 128 + (s2 * 2 + h) * 32 + i) * 8);
+            const uint4 q = *reinterpret_cast<const uint4 *>(
+                w + ((size_t)((tg.wsel[p] * 2 + s2) * 2 + h) * tg.kp + tg.koff + i) * 8);
             bw[p][s2] = *reinterpret_cast<const i32x4 *>(&q);
         }
     // staging slots (column constants): byte offset inside an input plane -- 0xfffffff0 for parts outside the (y, x) plane:
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias) b4 = *reinterpret_cast<const float4 *>(bias + 8 * rg + 4 * h);
+            if (bias) b4 = *reinterpret_cast<const float4 *>(bias + tg.koff + 8 * rg + 4 * h);
             bq[rg] = u32x4{__float_as_uint(b4.x), __float_as_uint(b4.y), __float_as_uint(b4.z), __float_as_uint(b4.w)};
         }
         if (wave == 0) {
@@ -1271,10 +1273,13 @@ static int num_cus16() {
 
 // -1: not this kernel's shape
 static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsigned short *w, const float *bias,
-                         unsigned short *y1, hipStream_t s) {
+                         unsigned short *y1, unsigned short *y2, hipStream_t s) {
     static const int off = getenv("MVD_FWD16P") ? (atoi(getenv("MVD_FWD16P")) == 0) : 0;
     if (off) return -1;
-    if (g.C1 != 32 || g.C2 != 0 || g.K1 != 32 || g.K2 != 0 || g.ntaps != 27 || g.T != 27) return -1;
+    // 32 reduce channels; 32 produce channels, or 32 + 32 into two tensors (the input gradient of a conv that read two
+    // concatenated 32-channel tensors: two independent 32 -> 32 problems on the same dy; k_fwd16z only)
+    const bool two_out = g.K1 == 32 && g.K2 == 32 && y2 != nullptr;
+    if (g.C1 != 32 || g.C2 != 0 || g.K1 != 32 || (g.K2 != 0 && !two_out) || g.ntaps != 27 || g.T != 27) return -1;
     for (int a = 0; a < 3; a++)
         if (g.sa[a] != 1 || g.so[a] != 1 || g.oo[a] != 0) return -1;
     if (g.Dy != g.Do || g.Hy != g.Ho || g.Wy != g.Wo) return -1;
@@ -1366,9 +1371,16 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
                 configured_z = true;
             }
             const int per_xcd = (tz.nitems + 7) / 8;
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(per_xcd * 8)), dim3(256), (size_t)Z_LDS, s, g, tz, a1, w, bias, y1);
-            return check_launch("conv fwd16z (z-marching bf16 mfma, weights in registers)");
+            tz.kp = g.K1 + g.K2;
+            for (int q = 0; q < (two_out ? 2 : 1); q++) {
+                tz.koff = 32 * q;
+                hipLaunchKernelGGL(kfn, dim3((unsigned)(per_xcd * 8)), dim3(256), (size_t)Z_LDS, s, g, tz, a1, w, bias,
+                                   q ? y2 : y1);
+                if (check_launch("conv fwd16z (z-marching bf16 mfma, weights in registers)")) return 1;
+            }
+            return 0;
         }
+        if (two_out) return -1;
         static const int use_r = getenv("MVD_FWD16R") ? atoi(getenv("MVD_FWD16R")) : 0;
         if (ok && use_r) {
             static bool configured_r = false;
@@ -1403,6 +1415,7 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
             return check_launch("conv fwd16q (persistent bf16 mfma, weights in registers)");
         }
     }
+    if (two_out) return -1;
     const size_t lds = (size_t)P_WB + 2 * (size_t)P_HALO;
     static bool configured = false;
     if (!configured) {
@@ -1433,7 +1446,7 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
             if (g.off[t][a] > mx[a]) mx[a] = g.off[t][a];
         }
     {
-        int r = launch_fwd16p(g, a1, w, bias, y1, s);
+        int r = launch_fwd16p(g, a1, w, bias, y1, y2, s);
         if (r >= 0) return r;
     }
     const int NT = (K % 64 == 0) ? 2 : 1;
