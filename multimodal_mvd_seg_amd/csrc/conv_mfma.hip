@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd_mfma(const FwdGeom g, const FwdT
 #pragma unroll
             for (int u = 0; u < SB; u++) {
                 const int idx = base + u * 256 + tid;
-                if (idx < nw) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // (left undefined the array went to scratch memory: every load
+                if (idx < nw) {                          // waited for and parked there before the next one was issued)
                     const int row = idx / ROWV, j = idx - row * ROWV;
                     const int t = row >> 1, hh = row & 1;
                     if (L32)  // HH == 4: one float4 per output channel j, strided by the 16-float k rows of the CK=32 layout
