@@ -27,10 +27,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/roof_bf16 -- python
 cp $(ls $OUT/roof_bf16/*/*kernel_stats.csv | head -1) $OUT/${RR}_roofline_bf16_kernel_stats.csv
 tail -1 $OUT/roof_fp32.log | cut -c1-600; tail -1 $OUT/roof_bf16.log | cut -c1-600
 cd $ROOT
-LAYER=dec5.conv1 WHAT=fwd DTYPE=bf16 ITERS=10 TAG=${RR}_fwd16q tools/pmc_kernel.sh > $OUT/pmc_fwd16q.txt 2>&1 || true
+LAYER=dec5.conv1 WHAT=fwd DTYPE=bf16 ITERS=10 TAG=${RR}_fwd16z tools/pmc_kernel.sh > $OUT/pmc_fwd16z.txt 2>&1 || true
 LAYER=dec5.conv1 WHAT=wgrad DTYPE=bf16 ITERS=10 TAG=${RR}_wgrad16 tools/pmc_kernel.sh > $OUT/pmc_wgrad16.txt 2>&1 || true
 LAYER=dec5.conv0 WHAT=fwd DTYPE=fp32 ITERS=5 TAG=${RR}_fwd_wino2 tools/pmc_kernel.sh > $OUT/pmc_fwd_wino2.txt 2>&1 || true
-cp gpurun_out/pmc_${RR}_fwd16q/summary.txt $OUT/${RR}_pmc_fwd16q_summary.txt || true
+cp gpurun_out/pmc_${RR}_fwd16z/summary.txt $OUT/${RR}_pmc_fwd16z_summary.txt || true
 cp gpurun_out/pmc_${RR}_wgrad16/summary.txt $OUT/${RR}_pmc_wgrad16_summary.txt || true
 cp gpurun_out/pmc_${RR}_fwd_wino2/summary.txt $OUT/${RR}_pmc_fwd_wino2_summary.txt || true
 echo collected
