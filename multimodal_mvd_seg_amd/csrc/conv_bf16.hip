@@ -72,6 +72,9 @@ struct Fwd16Tile {
 // SWZ (unit gather stride in every axis): halo slots are the bare 64-byte voxel rows with the four 16-byte parts XOR-swizzled
 // by (halo y-row & 3) -- conflict-free ds_read_b128 for every tap (see k_fwd16q); the padded 80-byte slots of the
 // strided layers are 3-way conflicted on unit-stride problems (PMC round 2: as many conflict cycles as access cycles).
+#ifndef MVD_F16_DBG
+#define MVD_F16_DBG 0
+#endif
 template <int NT, int MT, int TG, int XR, bool SWZ>
 __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
                                                   const unsigned short *__restrict__ a2,
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
             for (int r = 0; r < 16; r++) acc[m][q][r] = 0.f;
 
     // weight group: fragment index f = u*256 + tid = ((tl*2 + s)*2 + hh)*KT + k ; tl is a compile-time function of u
-    uint4 wr[WR];
+    uint4 wr[2][WR];  // two groups of weights in flight (round 2): a group's loads have two groups of MFMAs to land
     int woff[WR];
     constexpr int FPT = 4 * KT;  // fragments per tap
 #pragma unroll
@@ -134,25 +137,30 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
         const int k = f % KT, sh = f / KT;  // sh = s*2 + hh
         woff[u] = (sh * tg.K + kb * KT + k) * 8;  // element offset inside a (chunk, tap) block of 4*K*8 elements
     }
-    auto load_w = [&](int cc, int gidx) {
+    auto load_w = [&](int cc, int gidx, uint4(&dst)[WR]) {
 #pragma unroll
         for (int u = 0; u < WR; u++) {
             // tap of slot u: FPT = 256 -> u; FPT = 128 -> 2u + (tid >> 7): uniform per wave either way
             const int t = __builtin_amdgcn_readfirstlane(gidx * TG + (u * 256 + tid) / FPT);
-            wr[u] = make_uint4(0, 0, 0, 0);
+            dst[u] = make_uint4(0, 0, 0, 0);
             if (t < g.ntaps) {
                 const int wt = g.wt[t];
-                wr[u] = *reinterpret_cast<const uint4 *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8 + woff[u]);
+                dst[u] = *reinterpret_cast<const uint4 *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8 + woff[u]);
             }
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, const uint4(&src)[WR]) {
 #pragma unroll
         for (int u = 0; u < WR; u++)
-            *reinterpret_cast<uint4 *>(Wsm + (size_t)buf * WBUF + (size_t)(u * 256 + tid) * WROW) = wr[u];
+            *reinterpret_cast<uint4 *>(Wsm + (size_t)buf * WBUF + (size_t)(u * 256 + tid) * WROW) = src[u];
     };
 
     const int cc_begin = split * nch / tg.S, cc_end = (split + 1) * nch / tg.S;
+    // every workgroup streams the same few hundred KB of weights from L2, and workgroups launched together walk them in
+    // step: the tap groups are taken in an order rotated by the work item, so that at any time the CUs of an XCD ask for
+    // different lines (ablation round 2: the weight path was 64 of the 118 us this kernel needs WITHOUT its MFMAs on
+    // 64 -> 64 @64^3 -- 450 MB of L2 reads per launch)
+    const int rot = item % ngroups;
     for (int cc = cc_begin; cc < cc_end; cc++) {
         const int c0 = cc * 32;
         const unsigned short *src;
@@ -162,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
         } else {
             src = a2; Cs = g.C2; cofs = c0 - g.C1;
         }
-        load_w(cc, 0);
+        load_w(cc, rot, wr[0]);
+        if (ngroups > 1) load_w(cc, (rot + 1) % ngroups, wr[1]);
         __syncthreads();  // B1: every wave is done with the previous chunk's LDS
         {
             uint4 v[XR];
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                     const int ez = (slot * tg.magHW) >> 20, rem = slot - ez * EHW;
                     const int ey = (rem * tg.magW) >> 20, ex = rem - ey * tg.EW;
                     const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
-                    if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                    if (!(MVD_F16_DBG & 16) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
                         v[u] = *reinterpret_cast<const uint4 *>(
                             src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid & 3) * 8);
                 }
@@ -192,11 +201,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                 *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * XS + part * 16) = v[u];
             }
         }
-        for (int gi = 0; gi < ngroups; gi++) {
-            store_w(gi & 1);
-            __syncthreads();  // B2
-            if (gi + 1 < ngroups) load_w(cc, gi + 1);
-            const unsigned char *wb_ = Wsm + (size_t)(gi & 1) * WBUF;
+        auto group_mfmas = [&](int gi, int wbuf) __attribute__((always_inline)) {
+            const unsigned char *wb_ = Wsm + (size_t)wbuf * WBUF;
             // operand registers are double buffered over the 2*TG (tap, k-step) slots of the group: the fragments of
             // slot j+1 are read from LDS before slot j's MFMAs are issued, so a register an in-flight MFMA still reads
             // is never the target of the next ds_read (tools/probes/mfma_probe.hip: 111 -> 137 TFLOP/s effect)
@@ -217,10 +223,17 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                     bfr[buf][q_] = *reinterpret_cast<bf16x8 *>(&q);
                 }
             };
+#if (MVD_F16_DBG & 4)
+            if (gi == 0)
+#endif
             read_ops(0, 0);
 #pragma unroll
             for (int j = 0; j < 2 * TG; j++) {
+#if (MVD_F16_DBG & 4)
+                if (gi == 0)
+#endif
                 if (j + 1 < 2 * TG) read_ops(j + 1, (j + 1) & 1);
+#if !(MVD_F16_DBG & 2)
                 if (gi * TG + (j >> 1) < g.ntaps) {  // block-uniform
 #pragma unroll
                     for (int m = 0; m < MT; m++)
@@ -228,6 +241,27 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                         for (int q_ = 0; q_ < NT; q_++)
                             acc[m][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j & 1][q_], af[j & 1][m], acc[m][q_], 0, 0, 0);
                 }
+#endif
+            }
+        };
+        // group gi: its weights (loaded two groups ago into register set gi & 1) go to LDS buffer gi & 1 -- last read by
+        // group gi-2, which every wave left before the barrier of group gi-1 -- and the freed registers take group gi+2.
+        // With one register set the loads of group gi+1 had only group gi's 24 MFMAs (~0.4 us) to come back from L2.
+        for (int gi = 0; gi < ngroups; gi += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                const int gj = gi + par;
+                if (gj >= ngroups) break;
+#if !(MVD_F16_DBG & 8)
+                store_w(par, wr[par]);
+#endif
+#if !(MVD_F16_DBG & 1)
+                __syncthreads();  // B2
+#endif
+#if !(MVD_F16_DBG & 8)
+                if (gj + 2 < ngroups) load_w(cc, (gj + 2 + rot) % ngroups, wr[par]);
+#endif
+                group_mfmas((gj + rot) % ngroups, par);
             }
         }
     }
