@@ -1,6 +1,6 @@
 """Child process of tests/test_gpu_ddp.py: one data-parallel rank running nnUNetTrainerMI355.train_step.
 
-usage: python tests/ddp_worker.py BACKEND RANK WORLD PORT OUT_DIR STEPS
+usage: python tests/ddp_worker.py BACKEND RANK WORLD PORT OUT_DIR STEPS [PRECISION]
 Every rank uses cuda:0 (the test box has one GPU; on a real node LOCAL_RANK picks the device).  The process is started
 fresh (no HIP call before torch.distributed is up), joins the group, builds the trainer the way the reference's run_ddp
 does (run_training.py:152-183: init_process_group, set_device, trainer.initialize -> DDP wrap) and writes what the
@@ -12,13 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_trainer(batch_size, device):
+def build_trainer(batch_size, device, precision="fp32"):
     from multimodal_mvd_seg_amd import trainer
     strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
     plans = trainer.make_plans((32, 32, 32), strides, batch_size=batch_size)   # features 32 / 64 / 128: MFMA engines
     ds = {"channel_names": {str(i): str(i) for i in range(4)},
           "labels": {"background": 0, "a": 1, "b": 2, "c": 3, "d": 4}}
-    return trainer.nnUNetTrainerMI355(plans, "3d_fullres", 0, ds, device=device)
+    tr = trainer.nnUNetTrainerMI355(plans, "3d_fullres", 0, ds, device=device)
+    tr.precision = precision
+    return tr
 
 
 def rank_batch(tr, rank):
@@ -34,6 +36,7 @@ def rank_batch(tr, rank):
 def main():
     backend, rank, world, port, out_dir, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], \
         sys.argv[5], int(sys.argv[6])
+    precision = sys.argv[7] if len(sys.argv) > 7 else "fp32"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
@@ -44,7 +47,7 @@ def main():
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         torch.manual_seed(100 + rank)          # different init per rank: the DDP wrap must broadcast rank 0's weights
-        tr = build_trainer(2, dev)             # GLOBAL batch 2 -> 1 sample per rank at world 2
+        tr = build_trainer(2, dev, precision)  # GLOBAL batch 2 -> 1 sample per rank at world 2
         tr.ddp_bucket_bytes = 2 << 20          # the 3-stage test network has 11 MB of gradients: several buckets
         tr.initialize()
         assert tr.is_ddp and tr.batch_size == 2 // world
