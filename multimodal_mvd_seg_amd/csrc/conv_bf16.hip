@@ -90,6 +90,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     static_assert((TG * 4 * KT) % 256 == 0, "weight group must be a multiple of 256 fragments");
     unsigned char *Xs = lds8;
     unsigned char *Wsm = lds8 + (size_t)XR * 64 * XS;  // halo buffer sized for XR*64 >= nslots slots
+    // Per-tap tables in LDS (round 2): tab[t] = halo byte offset of tap t, tab[32 + t] = its index in the packed weights.
+    // Read out of the kernel argument they were an s_load (+ a byte load for wt) per tap INSIDE the MFMA loop, each
+    // followed by s_waitcnt lgkmcnt(0) -- SMEM returns out of order, so the wait also drained every operand read in
+    // flight: a scalar-memory round trip per 8 MFMAs.
+    int *tab = reinterpret_cast<int *>(Wsm + 2 * (size_t)WBUF);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,6 +110,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     const int td_ = (int)(r_ % (unsigned)tg.ntd);
     const int n = (int)(r_ / (unsigned)tg.ntd);
 
+    if (tid < 32) {
+        const int tc = tid < g.ntaps ? tid : g.ntaps - 1;
+        tab[tid] = tg.toff[tc] * XS;
+        tab[32 + tid] = tid < g.ntaps ? (int)g.wt[tc] : -1;  // -1: past the last tap (zero weights)
+    }
+    __syncthreads();
     const int C = g.C1 + g.C2;
     const int nch = C / 32;
     const int ngroups = (g.ntaps + TG - 1) / TG;
@@ -141,12 +152,10 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
 #pragma unroll
         for (int u = 0; u < WR; u++) {
             // tap of slot u: FPT = 256 -> u; FPT = 128 -> 2u + (tid >> 7): uniform per wave either way
-            const int t = __builtin_amdgcn_readfirstlane(gidx * TG + (u * 256 + tid) / FPT);
+            const int t = __builtin_amdgcn_readfirstlane(gidx * TG + (u * 256 + tid) / FPT);  // < 32
+            const int wt = tab[32 + t];
             dst[u] = make_uint4(0, 0, 0, 0);
-            if (t < g.ntaps) {
-                const int wt = g.wt[t];
-                dst[u] = *reinterpret_cast<const uint4 *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8 + woff[u]);
-            }
+            if (wt >= 0) dst[u] = *reinterpret_cast<const uint4 *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8 + woff[u]);
         }
     };
     auto store_w = [&](int buf, const uint4(&src)[WR]) {
@@ -207,10 +216,13 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
             // slot j+1 are read from LDS before slot j's MFMAs are issued, so a register an in-flight MFMA still reads
             // is never the target of the next ds_read (tools/probes/mfma_probe.hip: 111 -> 137 TFLOP/s effect)
             bf16x8 af[2][MT], bfr[2][NT];
+            int to3[TG];
+#pragma unroll
+            for (int tl = 0; tl < TG; tl++) to3[tl] = tab[gi * TG + tl];  // (clamped to the last tap when the table was built)
             auto read_ops = [&](int j, int buf) {
                 const int tl = j >> 1, s = j & 1;
-                const int t = gi * TG + tl < g.ntaps ? gi * TG + tl : g.ntaps - 1;  // block-uniform clamp
-                const int to = tg.toff[t] * XS;
+                const int to = to3[tl];
+                const int t = gi * TG + tl < g.ntaps ? gi * TG + tl : g.ntaps - 1;  // (SWZ only)
                 const int xo = SWZ ? ((((s << 1) | h) ^ ((ylq + tg.tdy[t]) & 3)) << 4) : s * 32;
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                     }
                     const uint4 img = pair_store_image(pk[0], pk[1]);
                     const int k = kb * KT + q * 32 + 16 * kp + 8 * h;  // first of this lane's 8 consecutive channels
-                    if (inside) {
+                    if (inside && !(MVD_F16_DBG & 32)) {
                         if (k < g.K1)
                             *reinterpret_cast<uint4 *>(y1 + ov * g.K1 + k) = img;
                         else
@@ -349,7 +361,7 @@ static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a
                         const unsigned short *w, const float *bias, unsigned short *y1, unsigned short *y2, void *ws,
                         size_t ws_bytes, hipStream_t s) {
     auto kern = k_fwd16<NT, MT, TG, XR, SWZ>;
-    const size_t lds = (size_t)XR * 64 * (SWZ ? 64 : 80) + 2 * (size_t)TG * 4 * (32 * NT) * 16;
+    const size_t lds = (size_t)XR * 64 * (SWZ ? 64 : 80) + 2 * (size_t)TG * 4 * (32 * NT) * 16 + 256;  // + tap tables
     if (lds > LDS_LIMIT16) return -1;
     static bool configured = false;
     if (!configured) {
