@@ -346,6 +346,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][q][r] = 0.f;
 
+    // Per-tap tables across the lanes of a wave (lane t: halo offset and packed-weight index of tap t), read back with
+    // v_readlane inside the loops (round 2).  Indexed out of the kernel argument they were an s_load per tap in the MFMA
+    // loop, each followed by s_waitcnt lgkmcnt(0) -- which also drains every LDS operand read in flight.
+    const int lt = lane < g.ntaps ? lane : g.ntaps - 1;
+    const int toff_l = tg.toff[lt < 27 ? lt : 26], wt_l = g.wt[lt < 27 ? lt : 26];
     float4 wr[WR];
     // weight group `gidx` of chunk `cc` -> registers.  float4 index inside the group: idx = u*256 + tid =
     // ((tl*2+hh)*KT + k)*4 + e4; with 256 threads the tap of slot u is a compile-time function of u, so the tap id is
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
             const int t = gidx * TG + tl;  // uniform
             wr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t < g.ntaps && !(tg.dbg & 1)) {
-                const int wt = g.wt[t];
+                const int wt = __builtin_amdgcn_readlane(wt_l, t);
                 wr[u] = *reinterpret_cast<const float4 *>(w + ((size_t)cc * g.T + wt) * 2 * tg.K * 16 + woff[u]);
             }
         }
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
                 for (int tl = 0; tl < TG; tl++) {
                     const int t = gi * TG + tl;
                     if (t < g.ntaps) {  // block-uniform
-                        const int to = tg.toff[t];  // uniform index: scalar load
+                        const int to = __builtin_amdgcn_readlane(toff_l, t);
                         float4 af[MT][4], bf[NT][4];
 #pragma unroll
                         for (int m = 0; m < MT; m++) {
@@ -535,6 +540,9 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    // per-tap tables across the lanes, read back with v_readlane (see k_fwd32)
+    const int lt = lane < g.ntaps ? lane : g.ntaps - 1;
+    const int toff_l = tg.toff[lt < 27 ? lt : 26], wt_l = g.wt[lt < 27 ? lt : 26];
 
     for (int cc = 0; cc < nch; cc++) {
         const int c0 = cc * 32;
@@ -551,7 +559,8 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
 #pragma unroll
         for (int u = 0; u < 3; u++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) wb[u][e] = *reinterpret_cast<const float4 *>(wc + (size_t)g.wt[tb + u] * wtap + e * 4);
+            for (int e = 0; e < 4; e++)
+                wb[u][e] = *reinterpret_cast<const float4 *>(wc + (size_t)__builtin_amdgcn_readlane(wt_l, tb + u) * wtap + e * 4);
         __syncthreads();
         if (fastst) {
             const unsigned off0 = (unsigned)(((iy0 + r3) * g.Wi + iw) * Cs + cofs + part * 4) << 2;  // bytes, used when ok
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
         // an in-flight MFMA reads is never the target of the next tap's ds_read
         float4 af[2][4];
         {
-            const float4 *pa = xlane + (size_t)tg.toff[tb] * (XS / 4);
+            const float4 *pa = xlane + (size_t)__builtin_amdgcn_readlane(toff_l, tb) * (XS / 4);
 #pragma unroll
             for (int e = 0; e < 4; e++) af[0][e] = pa[e];
         }
@@ -620,8 +629,9 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
                     const int tn = sidx + 3 < nt ? t + 3 : tb + nt - 1;
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        wb[(u + 3) & 3][e] = *reinterpret_cast<const float4 *>(wc + (size_t)g.wt[tn] * wtap + e * 4);
-                    const float4 *pa = xlane + (size_t)tg.toff[sidx + 1 < nt ? t + 1 : tb + nt - 1] * (XS / 4);
+                        wb[(u + 3) & 3][e] =
+                            *reinterpret_cast<const float4 *>(wc + (size_t)__builtin_amdgcn_readlane(wt_l, tn) * wtap + e * 4);
+                    const float4 *pa = xlane + (size_t)__builtin_amdgcn_readlane(toff_l, sidx + 1 < nt ? t + 1 : tb + nt - 1) * (XS / 4);
 #pragma unroll
                     for (int e = 0; e < 4; e++) af[(u + 1) & 1][e] = pa[e];
 #pragma unroll
