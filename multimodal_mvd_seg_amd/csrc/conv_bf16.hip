@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     // different lines (ablation round 2: the weight path was 64 of the 118 us this kernel needs WITHOUT its MFMAs on
     // 64 -> 64 @64^3 -- 450 MB of L2 reads per launch)
     const int rot = item % ngroups;
+    const bool fullg = ngroups * TG == g.ntaps;  // every group has TG taps (27 taps, TG = 3): no per-slot tap tests
     for (int cc = cc_begin; cc < cc_end; cc++) {
         const int c0 = cc * 32;
         const unsigned short *src;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
 #endif
                 if (j + 1 < 2 * TG) read_ops(j + 1, (j + 1) & 1);
 #if !(MVD_F16_DBG & 2)
-                if (gi * TG + (j >> 1) < g.ntaps) {  // block-uniform
+                if (fullg || gi * TG + (j >> 1) < g.ntaps) {  // block-uniform
 #pragma unroll
                     for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -259,6 +260,8 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
         // group gi: its weights (loaded two groups ago into register set gi & 1) go to LDS buffer gi & 1 -- last read by
         // group gi-2, which every wave left before the barrier of group gi-1 -- and the freed registers take group gi+2.
         // With one register set the loads of group gi+1 had only group gi's 24 MFMAs (~0.4 us) to come back from L2.
+        int gr = rot, gr2 = rot + 2 >= ngroups ? rot + 2 - ngroups : rot + 2;  // rotated indices of groups gj and gj + 2
+        if (gr2 >= ngroups) gr2 -= ngroups;                                     // (ngroups == 1)
         for (int gi = 0; gi < ngroups; gi += 2) {
 #pragma unroll
             for (int par = 0; par < 2; par++) {
@@ -271,9 +274,11 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
                 __syncthreads();  // B2
 #endif
 #if !(MVD_F16_DBG & 8)
-                if (gj + 2 < ngroups) load_w(cc, (gj + 2 + rot) % ngroups, wr[par]);
+                if (gj + 2 < ngroups) load_w(cc, gr2, wr[par]);
 #endif
-                group_mfmas((gj + rot) % ngroups, par);
+                group_mfmas(gr, par);
+                gr = gr + 1 == ngroups ? 0 : gr + 1;
+                gr2 = gr2 + 1 == ngroups ? 0 : gr2 + 1;
             }
         }
     }
