@@ -2367,10 +2367,20 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         }
     // tile shapes (powers of two), largest first.  Two register/LDS configurations: (NA, NB) = (13, 4) for halo-heavy
     // A (3x3x3 convs) and (2, 16) for halo-heavy B (transposed convs); both leave room for two workgroups per CU.
-    const int cand[4][3] = {{2, 8, 8}, {2, 4, 8}, {2, 4, 4}, {1, 4, 4}};
+    const int cand[5][3] = {{4, 8, 8}, {2, 8, 8}, {2, 4, 8}, {2, 4, 4}, {1, 4, 4}};
+    // bf16, 3x3x3 stride 1 on large volumes: 256-voxel tiles (MVD_WGRAD16_BIG=0: 128) -- half the barriers and staging
+    // per MFMA, a 6x10x10 halo for 256 voxels instead of 4x10x10 for 128
+    static const int big16 = getenv("MVD_WGRAD16_BIG") ? atoi(getenv("MVD_WGRAD16_BIG")) : 1;
     int cfg = -1;
-    for (int ci = 0; ci < 4 && cfg < 0; ci++) {
+    for (int ci = 0; ci < 5 && cfg < 0; ci++) {
         const int T3[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
+        if (ci == 0) {
+            bool plain27 = bf16_in && big16 && g.ntaps == 27 && (long)g.N * g.Do * g.Ho * g.Wo >= (1L << 15);
+            for (int a = 0; a < 3; a++) plain27 = plain27 && g.sa[a] == 1 && g.sb[a] == 1;
+            for (int t = 1; t < g.ntaps && plain27; t++)
+                for (int a = 0; a < 3; a++) plain27 = plain27 && g.ob[t][a] == g.ob[0][a];
+            if (!plain27) continue;
+        }
         int EA[3], EB[3];
         for (int a = 0; a < 3; a++) {
             EA[a] = (T3[a] - 1) * g.sa[a] + (mxA[a] - mnA[a]) + 1;
@@ -2378,8 +2388,10 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         }
         const int nA = EA[0] * EA[1] * EA[2], nB = EB[0] * EB[1] * EB[2];
         int c = -1;
-        if (bf16_in) {  // k_wgrad16: 64 slots per uint4-per-thread; (NA, NB) = (7, 2) or (1, 8)
-            if (nA <= 7 * 64 && nB <= 2 * 64) c = 0;
+        if (bf16_in) {  // k_wgrad16: 64 slots per uint4-per-thread; (NA, NB) = (10, 4) [256-voxel tile], (7, 2) or (1, 8)
+            if (ci == 0) {
+                if (nA <= 10 * 64 && nB <= 4 * 64) c = 2;
+            } else if (nA <= 7 * 64 && nB <= 2 * 64) c = 0;
             else if (nA <= 1 * 64 && nB <= 8 * 64) c = 1;
         } else if (nA * 8 <= 13 * 256 && nB * 8 <= 4 * 256) c = 0;   // k_wgrad_mfma<.., 7, 2, ..>: 7 x 512 / 2 x 512 float4
         else if (nA * 8 <= 2 * 256 && nB * 8 <= 16 * 256) c = 1;      // k_wgrad_mfma<.., 1, 8, ..>
@@ -2400,8 +2412,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
             return m;
         };
         const int EAhw = tg.EAh * tg.EAw, EBhw = tg.EBh * tg.EBw;
-        const int nmaxA = bf16_in ? (cfg == 0 ? 7 : 1) * 64 : (cfg == 0 ? 13 : 2) * 32;
-        const int nmaxB = bf16_in ? (cfg == 0 ? 2 : 8) * 64 : (cfg == 0 ? 4 : 16) * 32;
+        const int nmaxA = bf16_in ? (cfg == 2 ? 10 : cfg == 0 ? 7 : 1) * 64 : (cfg == 0 ? 13 : 2) * 32;
+        const int nmaxB = bf16_in ? (cfg == 2 ? 4 : cfg == 0 ? 2 : 8) * 64 : (cfg == 0 ? 4 : 16) * 32;
         tg.magAhw = magic(EAhw, nmaxA); tg.magAw = magic(tg.EAw, EAhw);
         tg.magBhw = magic(EBhw, nmaxB); tg.magBw = magic(tg.EBw, EBhw);
         if (tg.magAhw < 0 || tg.magAw < 0 || tg.magBhw < 0 || tg.magBw < 0) return -1;
@@ -2461,12 +2473,12 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         const unsigned short *hb = reinterpret_cast<const unsigned short *>(b);
         // bias gradient from the idle 28th tap slot (k_wgrad16): 27 taps, 7 slots per wave, one dy fragment for all taps
         float *pbias16 = nullptr;
-        if (dbias && dbias_done && cfg == 0 && sameB && tpw == 7 && g.ntaps < 28 &&
+        if (dbias && dbias_done && (cfg == 0 || cfg == 2) && sameB && tpw == 7 && g.ntaps < 28 &&
             need_ws + (size_t)tg.nsplit * g.K * sizeof(float) <= ws_bytes)
             pbias16 = partial + need_ws / sizeof(float);
 #define WG16(TPW, NA, NB, SH)                                                                                              \
-    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096 + 8192, s, g, tg, h1, h2, hb, \
-                       partial, (TPW) == 7 && (SH) == 1 ? pbias16 : nullptr)
+    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096 + (size_t)(tg.TD * tg.TH * tg.TW) * 64, \
+                       s, g, tg, h1, h2, hb, partial, (TPW) == 7 && (SH) == 1 ? pbias16 : nullptr)
 #define WG16_TPW(NA, NB, SH)                  \
     {                                         \
         if (tpw <= 1) WG16(1, NA, NB, SH);    \
@@ -2474,7 +2486,18 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         else if (tpw <= 4) WG16(4, NA, NB, SH); \
         else WG16(7, NA, NB, SH);             \
     }
-        if (cfg == 0) {
+        if (cfg == 2) {  // (chosen only for 27 taps, stride 1, one dy slot for all taps: sameB, tpw == 7)
+            static bool cfgd_big = false;
+            if (!cfgd_big) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad16<7, 10, 4, 1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) {
+                    set_error("conv wgrad (bf16 mfma): cannot raise the dynamic LDS limit");
+                    return 1;
+                }
+                cfgd_big = true;
+            }
+            WG16(7, 10, 4, 1);
+        } else if (cfg == 0) {
             if (sameB) WG16_TPW(7, 2, 1)
             else WG16_TPW(7, 2, 0)
         } else {
