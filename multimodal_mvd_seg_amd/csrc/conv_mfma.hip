@@ -2239,20 +2239,43 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
         __syncthreads();
         const int next = tile + tg.nsplit;
         if (next < tg.ntiles) load_tile(next);
-        for (int s16 = 0; s16 < TV; s16 += 16) {  // TV is a multiple of 16 for every tile shape
+        // operands of step s+1 are fetched (step-table read, address adds, transposing reads) before the MFMAs of step s
+        // are issued, into the other half of a double buffer: un-pipelined, every step exposed two LDS round trips
+        // (table, then operands: s_waitcnt lgkmcnt(0) twice) and 16 address adds in front of its 7 MFMAs
+        bf16x8w av[2][NAV], bv[2][NBV];
+        auto fetch = [&](int s16, int buf) {
             const int4 t4 = steptab[(s16 >> 4) * 64 + lane];
             const int sa_[2] = {t4.x, t4.y}, sb_[2] = {t4.z, t4.w};
-            bf16x8w av[NAV], bv[NBV];
 #pragma unroll
             for (int j = 0; j < NAV; j++) {
-                if (SH == 1 && j == TPW - 1 && ones_slot) av[j] = ones;  // wave-uniform
-                else av[j] = tr_operand(As + sa_[0] + aoff[j], As + sa_[1] + aoff[j]);
+                if (SH == 1 && j == TPW - 1 && ones_slot) av[buf][j] = ones;  // wave-uniform
+                else av[buf][j] = tr_operand(As + sa_[0] + aoff[j], As + sa_[1] + aoff[j]);
             }
 #pragma unroll
-            for (int j = 0; j < NBV; j++) bv[j] = tr_operand(Bs + sb_[0] + boff[j], Bs + sb_[1] + boff[j]);
+            for (int j = 0; j < NBV; j++) bv[buf][j] = tr_operand(Bs + sb_[0] + boff[j], Bs + sb_[1] + boff[j]);
+        };
+        constexpr bool PIPE = NA < 10;  // (the 256-voxel tile has no registers left for the second operand set)
+        if (PIPE) {
+            fetch(0, 0);
+            for (int s16 = 0; s16 < TV; s16 += 32) {  // TV is a multiple of 16
 #pragma unroll
-            for (int j = 0; j < TPW; j++)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[SH == 2 ? 0 : j], bv[SH == 1 ? 0 : j], acc[j], 0, 0, 0);
+                for (int par = 0; par < 2; par++) {
+                    const int sc = s16 + 16 * par;
+                    if (sc >= TV) break;
+                    if (sc + 16 < TV) fetch(sc + 16, par ^ 1);
+#pragma unroll
+                    for (int j = 0; j < TPW; j++)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[par][SH == 2 ? 0 : j], bv[par][SH == 1 ? 0 : j], acc[j], 0, 0,
+                                                                         0);
+                }
+            }
+        } else {
+            for (int s16 = 0; s16 < TV; s16 += 16) {
+                fetch(s16, 0);
+#pragma unroll
+                for (int j = 0; j < TPW; j++)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][SH == 2 ? 0 : j], bv[0][SH == 1 ? 0 : j], acc[j], 0, 0, 0);
+            }
         }
         tile = next;
     }
