@@ -75,21 +75,22 @@ struct Fwd16Tile {
 #ifndef MVD_F16_DBG
 #define MVD_F16_DBG 0
 #endif
-template <int NT, int MT, int TG, int XR, bool SWZ>
-__global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
+template <int NT, int MT, int TG, int XR, bool SWZ, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeom g, const Fwd16Tile tg, const unsigned short *__restrict__ a1,
                                                   const unsigned short *__restrict__ a2,
                                                   const unsigned short *__restrict__ w, const float *__restrict__ bias,
                                                   unsigned short *__restrict__ y1, unsigned short *__restrict__ y2,
                                                   float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     constexpr int KT = 32 * NT;
+    constexpr int TPB = NW * 64;                 // threads: wave w owns output plane od0 + w of the NW x (4 MT) x 8 tile
     constexpr int XS = SWZ ? 64 : 80;            // bytes per halo slot (64 + 16 pad when not swizzled)
     constexpr int WROW = 16;                     // bytes per (tap, s, h, k) weight fragment
-    constexpr int WR = TG * 4 * KT / 256;        // uint4 per thread per weight group (TG*2*2*KT fragments)
+    constexpr int WR = TG * 4 * KT / TPB;        // uint4 per thread per weight group (TG*2*2*KT fragments)
     constexpr int WBUF = TG * 4 * KT * WROW;     // bytes per weight buffer
-    static_assert((TG * 4 * KT) % 256 == 0, "weight group must be a multiple of 256 fragments");
+    static_assert((TG * 4 * KT) % TPB == 0, "weight group must be a multiple of the thread count");
     unsigned char *Xs = lds8;
-    unsigned char *Wsm = lds8 + (size_t)XR * 64 * XS;  // halo buffer sized for XR*64 >= nslots slots
+    unsigned char *Wsm = lds8 + (size_t)XR * (TPB / 4) * XS;  // halo buffer sized for XR*TPB/4 >= nslots slots
     // Per-tap tables in LDS (round 2): tab[t] = halo byte offset of tap t, tab[32 + t] = its index in the packed weights.
     // Read out of the kernel argument they were an s_load (+ a byte load for wt) per tap INSIDE the MFMA loop, each
     // followed by s_waitcnt lgkmcnt(0) -- SMEM returns out of order, so the wait also drained every operand read in
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     const int ngroups = (g.ntaps + TG - 1) / TG;
     const int EHW = tg.EH * tg.EW;
     const int nx = tg.nslots * 4;
-    const int od0 = td_ * 4, oh0 = th_ * (4 * MT), ow0 = tw_ * 8;
+    const int od0 = td_ * NW, oh0 = th_ * (4 * MT), ow0 = tw_ * 8;
     const int iz0 = od0 * g.sa[0] + tg.min_off[0], iy0 = oh0 * g.sa[1] + tg.min_off[1], ix0 = ow0 * g.sa[2] + tg.min_off[2];
 
     int sbase[MT];
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     constexpr int FPT = 4 * KT;  // fragments per tap
 #pragma unroll
     for (int u = 0; u < WR; u++) {
-        const int f = (u * 256 + tid) % FPT;
+        const int f = (u * TPB + tid) % FPT;
         const int k = f % KT, sh = f / KT;  // sh = s*2 + hh
         woff[u] = (sh * tg.K + kb * KT + k) * 8;  // element offset inside a (chunk, tap) block of 4*K*8 elements
     }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
 #pragma unroll
         for (int u = 0; u < WR; u++) {
             // tap of slot u: FPT = 256 -> u; FPT = 128 -> 2u + (tid >> 7): uniform per wave either way
-            const int t = __builtin_amdgcn_readfirstlane(gidx * TG + (u * 256 + tid) / FPT);  // < 32
+            const int t = __builtin_amdgcn_readfirstlane(gidx * TG + (u * TPB + tid) / FPT);  // < 32
             const int wt = tab[32 + t];
             dst[u] = make_uint4(0, 0, 0, 0);
             if (wt >= 0) dst[u] = *reinterpret_cast<const uint4 *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8 + woff[u]);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
     auto store_w = [&](int buf, const uint4(&src)[WR]) {
 #pragma unroll
         for (int u = 0; u < WR; u++)
-            *reinterpret_cast<uint4 *>(Wsm + (size_t)buf * WBUF + (size_t)(u * 256 + tid) * WROW) = src[u];
+            *reinterpret_cast<uint4 *>(Wsm + (size_t)buf * WBUF + (size_t)(u * TPB + tid) * WROW) = src[u];
     };
 
     const int cc_begin = split * nch / tg.S, cc_end = (split + 1) * nch / tg.S;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
             uint4 v[XR];
 #pragma unroll
             for (int u = 0; u < XR; u++) {
-                const int idx = u * 256 + tid;
+                const int idx = u * TPB + tid;
                 v[u] = make_uint4(0, 0, 0, 0);
                 if (idx < nx) {
                     const int slot = idx >> 2;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd16(const FwdGeom g, const Fwd16Ti
             }
 #pragma unroll
             for (int u = 0; u < XR; u++) {
-                const int idx = u * 256 + tid;
+                const int idx = u * TPB + tid;
                 int part = idx & 3;
                 if (SWZ) {
                     const int slot = idx >> 2;
@@ -361,12 +362,12 @@ __global__ void k_split_reduce16(const FwdGeom g, const float *__restrict__ part
 
 static const size_t LDS_LIMIT16 = 160 * 1024;
 
-template <int NT, int MT, int TG, int XR, bool SWZ>
+template <int NT, int MT, int TG, int XR, bool SWZ, int NW = 4>
 static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a1, const unsigned short *a2,
                         const unsigned short *w, const float *bias, unsigned short *y1, unsigned short *y2, void *ws,
                         size_t ws_bytes, hipStream_t s) {
-    auto kern = k_fwd16<NT, MT, TG, XR, SWZ>;
-    const size_t lds = (size_t)XR * 64 * (SWZ ? 64 : 80) + 2 * (size_t)TG * 4 * (32 * NT) * 16 + 256;  // + tap tables
+    auto kern = k_fwd16<NT, MT, TG, XR, SWZ, NW>;
+    const size_t lds = (size_t)XR * (NW * 16) * (SWZ ? 64 : 80) + 2 * (size_t)TG * 4 * (32 * NT) * 16 + 256;  // + tap tables
     if (lds > LDS_LIMIT16) return -1;
     static bool configured = false;
     if (!configured) {
@@ -397,7 +398,7 @@ static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a
     tg.nitems = (int)nitems;
     const long grid = ((nitems + 7) / 8) * 8;
     float *part = reinterpret_cast<float *>(ws);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, g, tg, a1, a2, w, bias, y1, y2, part);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, g, tg, a1, a2, w, bias, y1, y2, part);
     if (check_launch("conv fwd16 (bf16 mfma)")) return 1;
     if (S > 1) {
         long blocks = cdiv((long)out_elems, 256);
@@ -1508,6 +1509,36 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
             if (((n * m) >> 20) != n / d) return -1;
         return m;
     };
+    // 3x3x3 stride-1 layers with K % 64 == 0 and at least one 8x8x8 tile per CU: eight waves on a 512-voxel tile -- the
+    // weights of a chunk (the larger stream: 110 KB per 32 channels against a 38 KB halo) are fetched once per 512 voxels
+    // instead of once per 256, the halo shrinks from 2.34 to 1.95 bytes per byte used (MVD_FWD16_W8=0: four waves)
+    static const int w8 = getenv("MVD_FWD16_W8") ? atoi(getenv("MVD_FWD16_W8")) : 1;
+    bool unit3 = g.ntaps == 27;
+    for (int a = 0; a < 3; a++) unit3 = unit3 && g.sa[a] == 1 && mn[a] == -1 && mx[a] == 1;
+    if (w8 && unit3 && NT == 2 && g.Do >= 8) {
+        Fwd16Tile tg;
+        memset(&tg, 0, sizeof(tg));
+        tg.EH = 10; tg.EW = 10; tg.nslots = 1000;
+        for (int a = 0; a < 3; a++) tg.min_off[a] = mn[a];
+        tg.magHW = magic(100, 1024);
+        tg.magW = magic(10, 100);
+        for (int t = 0; t < g.ntaps; t++) {
+            tg.toff[t] = ((g.off[t][0] - mn[0]) * tg.EH + (g.off[t][1] - mn[1])) * tg.EW + (g.off[t][2] - mn[2]);
+            tg.tdy[t] = (signed char)(g.off[t][1] - mn[1]);
+        }
+        tg.ntd = (g.Do + 7) / 8;
+        tg.nth = (g.Ho + 7) / 8;
+        tg.ntw = (g.Wo + 7) / 8;
+        tg.K = K;
+        const long wgs8 = (long)g.N * tg.ntd * tg.nth * tg.ntw * (K / 64);
+        // measured (round 2, bench_conv --iters 40): 32^3 x 128..256 channels 0.060 / 0.110 ms against 0.064 / 0.117 with four
+        // waves; at 64^3 (>= 1024 workgroups) the two co-resident four-wave workgroups overlap better: 0.161 vs 0.160 forward,
+        // 0.150 vs 0.142 input gradient -- so only where a CU gets at most a few tiles
+        if (tg.magHW >= 0 && tg.magW >= 0 && wgs8 >= 256 && wgs8 < 1024) {
+            int r = launch_fwd16<2, 2, 4, 8, false, 8>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            if (r >= 0) return r;
+        }
+    }
     // tile candidates: 4x8x8 (MT = 2) when its halo fits 640 slots, else 4x4x8
     for (int MT = 2; MT >= 1; MT--) {
         Fwd16Tile tg;
