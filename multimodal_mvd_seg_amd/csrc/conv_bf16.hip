@@ -91,12 +91,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
     static_assert((TG * 4 * KT) % TPB == 0, "weight group must be a multiple of the thread count");
     unsigned char *Xs = lds8;
     unsigned char *Wsm = lds8 + (size_t)XR * (TPB / 4) * XS;  // halo buffer sized for XR*TPB/4 >= nslots slots
-    // Per-tap tables in LDS (round 2): tab[t] = halo byte offset of tap t, tab[32 + t] = its index in the packed weights.
-    // Read out of the kernel argument they were an s_load (+ a byte load for wt) per tap INSIDE the MFMA loop, each
-    // followed by s_waitcnt lgkmcnt(0) -- SMEM returns out of order, so the wait also drained every operand read in
-    // flight: a scalar-memory round trip per 8 MFMAs.
-    int *tab = reinterpret_cast<int *>(Wsm + 2 * (size_t)WBUF);
-
+    // Per-tap tables across the lanes of a wave (round 2): lane t holds the halo byte offset of tap t and its index in
+    // the packed weights; the loops read them back with v_readlane (a few cycles, result in an SGPR).  Indexed out of
+    // the kernel argument they were an s_load (+ a byte load) per tap INSIDE the MFMA loop, each followed by
+    // s_waitcnt lgkmcnt(0) -- SMEM returns out of order, so the wait also drained every operand read in flight.  (A
+    // first fix kept the tables in LDS: in-kernel s_memtime stamps then showed the three weight loads of a group taking
+    // ~900 cycles to ISSUE -- three serial LDS round trips, each in front of a 64-bit address computation.)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -111,12 +111,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
     const int td_ = (int)(r_ % (unsigned)tg.ntd);
     const int n = (int)(r_ / (unsigned)tg.ntd);
 
-    if (tid < 32) {
-        const int tc = tid < g.ntaps ? tid : g.ntaps - 1;
-        tab[tid] = tg.toff[tc] * XS;
-        tab[32 + tid] = tid < g.ntaps ? (int)g.wt[tc] : -1;  // -1: past the last tap (zero weights)
-    }
-    __syncthreads();
+    const int ltc = lane < g.ntaps ? lane : g.ntaps - 1;
+    const int toff_l = tg.toff[ltc < 27 ? ltc : 26] * XS;                 // (clamped to the last tap beyond ntaps)
+    const int wt_l = (int)g.wt[ltc < 27 ? ltc : 26];  // (slots past the last tap load the last tap's weights: their MFMAs are skipped)
     const int C = g.C1 + g.C2;
     const int nch = C / 32;
     const int ngroups = (g.ntaps + TG - 1) / TG;
@@ -140,23 +137,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
             for (int r = 0; r < 16; r++) acc[m][q][r] = 0.f;
 
     // weight group: fragment index f = u*256 + tid = ((tl*2 + s)*2 + hh)*KT + k ; tl is a compile-time function of u
-    uint4 wr[2][WR];  // two groups of weights in flight (round 2): a group's loads have two groups of MFMAs to land
-    int woff[WR];
+    uint4 wrA[WR], wrB[WR];  // two groups of weights in flight (round 2): a group's loads have two groups of MFMAs to land
+#pragma unroll
+    for (int u = 0; u < WR; u++) wrA[u] = wrB[u] = make_uint4(0, 0, 0, 0);  // (defined on every path: stays in registers)
+    unsigned woff[WR];
     constexpr int FPT = 4 * KT;  // fragments per tap
 #pragma unroll
     for (int u = 0; u < WR; u++) {
         const int f = (u * TPB + tid) % FPT;
         const int k = f % KT, sh = f / KT;  // sh = s*2 + hh
-        woff[u] = (sh * tg.K + kb * KT + k) * 8;  // element offset inside a (chunk, tap) block of 4*K*8 elements
+        woff[u] = (unsigned)((sh * tg.K + kb * KT + k) * 16);  // BYTE offset inside a (chunk, tap) block of 4*K*8 elements
     }
     auto load_w = [&](int cc, int gidx, uint4(&dst)[WR]) {
 #pragma unroll
         for (int u = 0; u < WR; u++) {
             // tap of slot u: FPT = 256 -> u; FPT = 128 -> 2u + (tid >> 7): uniform per wave either way
             const int t = __builtin_amdgcn_readfirstlane(gidx * TG + (u * TPB + tid) / FPT);  // < 32
-            const int wt = tab[32 + t];
-            dst[u] = make_uint4(0, 0, 0, 0);
-            if (wt >= 0) dst[u] = *reinterpret_cast<const uint4 *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8 + woff[u]);
+            const int wt = __builtin_amdgcn_readlane(wt_l, t);
+            // unconditional: with a branch around the load the compiler loses the vmcnt count and waits for vmcnt(0) in
+            // front of every weight store -- i.e. also for the group that was requested last.  Scalar base + 32-bit lane
+            // offset (the empty asm keeps the zero-extension next to the load: saddr addressing instead of a 64-bit
+            // multiply-add per load -- ~30 instructions per load made the three loads of a group take ~500 cycles to issue)
+            const char *wb_ = reinterpret_cast<const char *>(w + ((size_t)cc * g.T + wt) * 4 * tg.K * 8);
+            asm volatile("" : "+v"(woff[u]));
+            dst[u] = *reinterpret_cast<const uint4 *>(wb_ + woff[u]);
         }
     };
     auto store_w = [&](int buf, const uint4(&src)[WR]) {
@@ -170,6 +174,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
     // step: the tap groups are taken in an order rotated by the work item, so that at any time the CUs of an XCD ask for
     // different lines (ablation round 2: the weight path was 64 of the 118 us this kernel needs WITHOUT its MFMAs on
     // 64 -> 64 @64^3 -- 450 MB of L2 reads per launch)
+#if (MVD_F16_DBG & 64)
+    long long *stamps = reinterpret_cast<long long *>(part);  // diagnostic build only: in-kernel s_memtime stamps of one wave
+    int nst = 0;
+#endif
     const int rot = item % ngroups;
     const bool fullg = ngroups * TG == g.ntaps;  // every group has TG taps (27 taps, TG = 3): no per-slot tap tests
     for (int cc = cc_begin; cc < cc_end; cc++) {
@@ -181,8 +189,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
         } else {
             src = a2; Cs = g.C2; cofs = c0 - g.C1;
         }
-        load_w(cc, rot, wr[0]);
-        if (ngroups > 1) load_w(cc, (rot + 1) % ngroups, wr[1]);
+        load_w(cc, rot, wrA);
+        if (ngroups > 1) load_w(cc, (rot + 1) % ngroups, wrB);
         __syncthreads();  // B1: every wave is done with the previous chunk's LDS
         {
             uint4 v[XR];
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
             bf16x8 af[2][MT], bfr[2][NT];
             int to3[TG];
 #pragma unroll
-            for (int tl = 0; tl < TG; tl++) to3[tl] = tab[gi * TG + tl];  // (clamped to the last tap when the table was built)
+            for (int tl = 0; tl < TG; tl++) to3[tl] = __builtin_amdgcn_readlane(toff_l, gi * TG + tl);
             auto read_ops = [&](int j, int buf) {
                 const int tl = j >> 1, s = j & 1;
                 const int to = to3[tl];
@@ -263,25 +271,45 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
         // With one register set the loads of group gi+1 had only group gi's 24 MFMAs (~0.4 us) to come back from L2.
         int gr = rot, gr2 = rot + 2 >= ngroups ? rot + 2 - ngroups : rot + 2;  // rotated indices of groups gj and gj + 2
         if (gr2 >= ngroups) gr2 -= ngroups;                                     // (ngroups == 1)
-        for (int gi = 0; gi < ngroups; gi += 2) {
-#pragma unroll
-            for (int par = 0; par < 2; par++) {
-                const int gj = gi + par;
-                if (gj >= ngroups) break;
-#if !(MVD_F16_DBG & 8)
-                store_w(par, wr[par]);
+#if (MVD_F16_DBG & 64)
+#define MVD_STAMP(K) { if (stamp_on) { stamps[nst * 8 + (K)] = __builtin_amdgcn_s_memtime(); } }
+#else
+#define MVD_STAMP(K)
 #endif
-#if !(MVD_F16_DBG & 1)
-                __syncthreads();  // B2
-#endif
-#if !(MVD_F16_DBG & 8)
-                if (gj + 2 < ngroups) load_w(cc, gr2, wr[par]);
-#endif
-                group_mfmas(gr, par);
-                gr = gr + 1 == ngroups ? 0 : gr + 1;
-                gr2 = gr2 + 1 == ngroups ? 0 : gr2 + 1;
-            }
+        // one group: PAR = its LDS buffer / register set (two named arrays: an array of arrays went to scratch memory)
+#define MVD_F16_GROUP(PAR, WRX)                                                        \
+        {                                                                              \
+            MVD_F16_STAMP_ON                                                           \
+            MVD_STAMP(0)                                                               \
+            if (!(MVD_F16_DBG & 8)) store_w(PAR, WRX);                                 \
+            MVD_STAMP(1)                                                               \
+            if (!(MVD_F16_DBG & 1)) __syncthreads(); /* B2 */                          \
+            MVD_STAMP(2)                                                               \
+            if (!(MVD_F16_DBG & 8) && gj + 2 < ngroups) load_w(cc, gr2, WRX);          \
+            MVD_STAMP(3)                                                               \
+            group_mfmas(gr, PAR);                                                      \
+            MVD_STAMP(4)                                                               \
+            MVD_F16_STAMP_NEXT                                                         \
+            gr = gr + 1 == ngroups ? 0 : gr + 1;                                       \
+            gr2 = gr2 + 1 == ngroups ? 0 : gr2 + 1;                                    \
         }
+#if (MVD_F16_DBG & 64)
+#define MVD_F16_STAMP_ON const bool stamp_on = item == 64 && wave == 0 && lane == 0 && nst < 40;
+#define MVD_F16_STAMP_NEXT if (stamp_on) nst++;
+#else
+#define MVD_F16_STAMP_ON
+#define MVD_F16_STAMP_NEXT
+#endif
+        for (int gj = 0; gj < ngroups;) {
+            MVD_F16_GROUP(0, wrA)
+            if (++gj >= ngroups) break;
+            MVD_F16_GROUP(1, wrB)
+            ++gj;
+        }
+#undef MVD_F16_GROUP
+#undef MVD_F16_STAMP_ON
+#undef MVD_F16_STAMP_NEXT
+#undef MVD_STAMP
     }
     // epilogue.  The MFMA operands are swapped (D^T = W^T X^T): column (lane & 31) = voxel of the M tile, rows = output
     // channels (r & 3) + 8 * (r >> 2) + 4 * h -- a lane holds 4 x 4 consecutive channels of ONE voxel and stores them as
