@@ -115,6 +115,57 @@ __global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict
         if (k < K) logits[((size_t)n * K + k) * V + v] = acc[k] + bias[k];
 }
 
+// Deep levels (many channels, few voxels: 320 channels at 8^3 is 1024 threads looping over 320 channels each): P adjacent
+// lanes share a voxel, lane p takes the 32-channel chunks p, p + P, ...; the K partial sums meet by xor-shuffles (fixed
+// tree: deterministic).  A lane reads 128 (64) contiguous bytes per chunk, the P lanes of a voxel consecutive chunks.
+template <bool XB, int P>
+__global__ __launch_bounds__(256) void k_seghead_fwd_voxp(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ logits, long V,
+                                                          int C, int K) {
+    const int n = blockIdx.y;
+    const long gt = (long)blockIdx.x * 256 + threadIdx.x;
+    const long v = gt / P;
+    const int p = (int)(gt - v * P);
+    const bool live = v < V;
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) acc[k] = 0.f;
+    const size_t xo = ((size_t)n * V + (live ? v : 0)) * C;
+    for (int c0 = p * 32; c0 < C; c0 += 32 * P) {
+        float4 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            q[j] = (live && c0 + 4 * j < C) ? ld4<XB>(x, xo + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) {
+                const float *wk = w + (size_t)k * C + c0;
+                float a = acc[k];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (c0 + 4 * j < C) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(wk + 4 * j);
+                        a += q[j].x * w4.x;
+                        a += q[j].y * w4.y;
+                        a += q[j].z * w4.z;
+                        a += q[j].w * w4.w;
+                    }
+                acc[k] = a;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+        if (k < K) {
+#pragma unroll
+            for (int o = 1; o < P; o <<= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        }
+    if (live && p == 0) {
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            if (k < K) logits[((size_t)n * K + k) * V + v] = acc[k] + bias[k];
+    }
+}
+
 // dx: one thread per (quad of 4 consecutive voxels, 4-channel group): the K class gradients of the quad come in as one
 // float4 per class (planar dl), the thread's K x 4 weights stay in registers over its grid-stride loop, and the C/4 lanes
 // of a voxel write one full 128-byte line.  k order as in k_seghead_dx.  V % 4 == 0.
@@ -768,6 +819,19 @@ static int seghead_fwd_impl(const float *x, bool xb, const float *w, const float
                             int C, int K, void *stream) {
     MVD_REQUIRE(x && w && bias && logits, "seghead_fwd: null pointer");
     MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && K > 0 && K <= KMAX, "seghead_fwd: bad shape (K<=8)");
+    if (C % 32 == 0 && C >= 64 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (long)N * V < (1L << 20)) {
+        // few voxels, many channels: 2 / 4 / 8 lanes per voxel (>= 2 chunks of 32 channels per lane where C allows)
+        const int P = C >= 256 ? 8 : (C >= 128 ? 4 : 2);
+        const dim3 grid(cdiv(V * P, 256), N);
+#define MVD_SH_LAUNCH(PP)                                                                                                  \
+    hipLaunchKernelGGL((xb ? k_seghead_fwd_voxp<true, PP> : k_seghead_fwd_voxp<false, PP>), grid, dim3(256), 0, as_stream(stream), x, \
+                       w, bias, logits, V, C, K)
+        if (P == 8) MVD_SH_LAUNCH(8);
+        else if (P == 4) MVD_SH_LAUNCH(4);
+        else MVD_SH_LAUNCH(2);
+#undef MVD_SH_LAUNCH
+        return check_launch("seghead_fwd (lanes per voxel)");
+    }
     if (C % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
         auto kv = xb ? k_seghead_fwd_vox<true> : k_seghead_fwd_vox<false>;
         hipLaunchKernelGGL(kv, dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C, K);
