@@ -854,6 +854,9 @@ static long seghead_chunk(long total, int *nblk) {
     // (a software-pipelined loop -- next quad's loads under this quad's FMAs -- was tried in round 2 and ran 1.4-2x
     // SLOWER: 96 more registers per thread; what the pass lacked on the lower levels was workgroups, not overlap)
     long nb = total / 512;
+    // deep levels (8^3 ... 16^3: 1k - 8k voxels of 320 - 256 channels): 2 - 16 workgroups left the pass at 50 us for half a
+    // megabyte; chunks of 64 voxels give up to 128 workgroups there
+    if (nb < 128) nb = total / 64 < 128 ? total / 64 : 128;
     if (nb < 1) nb = 1;
     if (nb > 8192) nb = 8192;  // up to 32 workgroups per CU: the weight-gradient pass is a pure stream over x and dl
     long chunk = cdiv(total, nb);
