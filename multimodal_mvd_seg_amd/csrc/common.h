@@ -38,6 +38,19 @@ inline hipStream_t as_stream(void *s) {
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// A value loaded from memory, made "arrived" HERE: the empty volatile asm is a use the compiler must wait for, once and
+// unconditionally.  Without it a bias loaded at the top of an epilogue has its first use inside the predicated store
+// blocks, every such block gets an s_waitcnt vmcnt(0), and that also waits for the previous block's STORE: the stores
+// of a tile run as serialised write round trips (k_fwd_wino2: 23 of a tile's 85 kilocycles, tools/stamps_wino.py).
+__device__ __forceinline__ float settled(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float4 settled(float4 v) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    return v;
+}
+
 // bf16 storage helpers (uint16_t bit patterns).  f2bf: v_cvt_pk_bf16_f32, round-to-nearest-even, NaN preserved.
 __device__ inline unsigned short f2bf(float f) {
     __bf16 h = (__bf16)f;

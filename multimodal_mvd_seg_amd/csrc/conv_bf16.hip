@@ -316,6 +316,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
     // 8-byte bf16 packets (sixteen 2-byte stores per tile cost more than the tile's MFMAs)
     const int od = od0 + wave;
     if (od >= g.Do) return;  // wave-uniform
+    // the tile's bias values first, settled (common.h): loads between the stores would serialise them
+    float4 bq[NT][4];
+#pragma unroll
+    for (int q = 0; q < NT; q++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+            bq[q][rg] = (bias && tg.S == 1) ? *reinterpret_cast<const float4 *>(bias + kb * KT + q * 32 + 8 * rg + 4 * h)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < NT; q++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) bq[q][rg] = settled(bq[q][rg]);
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         const int oh = oh0 + 4 * m + (i >> 3), ow = ow0 + (i & 7);
@@ -340,14 +352,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const int rg = 2 * kp + e;
-                        const int k = kb * KT + q * 32 + 8 * rg + 4 * h;
-                        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (bias) {
-                            const float4 b4 = *reinterpret_cast<const float4 *>(bias + k);
-                            bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-                        }
-                        pk[e] = pack_bf16x4(acc[m][q][rg * 4 + 0] + bv[0], acc[m][q][rg * 4 + 1] + bv[1],
-                                            acc[m][q][rg * 4 + 2] + bv[2], acc[m][q][rg * 4 + 3] + bv[3]);
+                        const float4 b4 = bq[q][rg];
+                        pk[e] = pack_bf16x4(acc[m][q][rg * 4 + 0] + b4.x, acc[m][q][rg * 4 + 1] + b4.y,
+                                            acc[m][q][rg * 4 + 2] + b4.z, acc[m][q][rg * 4 + 3] + b4.w);
                     }
                     const uint4 img = pair_store_image(pk[0], pk[1]);
                     const int k = kb * KT + q * 32 + 16 * kp + 8 * h;  // first of this lane's 8 consecutive channels

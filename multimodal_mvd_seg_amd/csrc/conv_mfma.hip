@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd_mfma(const FwdGeom g, const FwdT
 #pragma unroll
         for (int q_ = 0; q_ < NT; q_++) {
             const int k = kb * KT + q_ * 32 + i;
-            const float bv = (bias && S == 1) ? bias[k] : 0.f;
+            const float bv = settled((bias && S == 1) ? bias[k] : 0.f);
             store_tile32(g, acc[m][q_], bv, n, od, oh0 + 4 * m, ow0, k, h, S, split, tg.K, part, y1, y2);
         }
 }
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void k_fwd32(const FwdGeom g, const Fwd32Ti
 #pragma unroll
         for (int q = 0; q < NT; q++) {
             const int k = kb * KT + q * 32 + i;
-            const float bv = (bias && tg.S == 1) ? bias[k] : 0.f;
+            const float bv = settled((bias && tg.S == 1) ? bias[k] : 0.f);
             store_tile32(g, acc[m][q], bv, n, od, oh0 + 4 * m, ow0, k, h, tg.S, split, tg.K, part, y1, y2);
         }
 }
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
     }
     const int od = od0 + dl;
     if (od >= g.Do) return;
-    const float bv = bias ? bias[kcol] : 0.f;
+    const float bv = settled(bias ? bias[kcol] : 0.f);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 4) void k_convT_fwd(const TranspGeom g, const 
         }
     }
     const int k = kb * 32 + i;
-    const float bv = bias ? bias[k] : 0.f;
+    const float bv = settled(bias ? bias[k] : 0.f);
     const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
     // output row index of THIS lane's voxel (two divisions, once); the accumulator rows a lane holds belong to other
     // lanes' voxels: fetched by a lane shuffle instead of 32 more divisions (the index math was the kernel's bottleneck)
@@ -266,6 +266,12 @@ __global__ __launch_bounds__(256, 4) void k_convT_fwd16(const TranspGeom g, cons
     // D^T layout (operands swapped): column (lane & 31) = this lane's own voxel, rows = output channels
     // (r & 3) + 8 * (r >> 2) + 4 * h: four 8-byte packets of 4 consecutive channels per position
     const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    float4 bq[4];  // the bias values first, settled (common.h): loads between the stores would serialise them
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++)
+        bq[rg] = bias ? *reinterpret_cast<const float4 *>(bias + kb * 32 + 8 * rg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) bq[rg] = settled(bq[rg]);
     if (vb + i < g.NV) {
         const long ob = out_base(g, (unsigned)v);
 #pragma unroll
@@ -276,14 +282,10 @@ __global__ __launch_bounds__(256, 4) void k_convT_fwd16(const TranspGeom g, cons
                 unsigned short *yo = y + (size_t)(ob + ((long)pd * Hy + ph) * Wy + pw) * g.K + kb * 32 + 4 * h;
 #pragma unroll
                 for (int rg = 0; rg < 4; rg++) {
-                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (bias) {
-                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + kb * 32 + 8 * rg + 4 * h);
-                        bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-                    }
+                    const float4 b4 = bq[rg];
                     uint2 q;
-                    q.x = (unsigned)f2bf(acc[j][rg * 4 + 0] + bv[0]) | ((unsigned)f2bf(acc[j][rg * 4 + 1] + bv[1]) << 16);
-                    q.y = (unsigned)f2bf(acc[j][rg * 4 + 2] + bv[2]) | ((unsigned)f2bf(acc[j][rg * 4 + 3] + bv[3]) << 16);
+                    q.x = (unsigned)f2bf(acc[j][rg * 4 + 0] + b4.x) | ((unsigned)f2bf(acc[j][rg * 4 + 1] + b4.y) << 16);
+                    q.y = (unsigned)f2bf(acc[j][rg * 4 + 2] + b4.z) | ((unsigned)f2bf(acc[j][rg * 4 + 3] + b4.w) << 16);
                     *reinterpret_cast<uint2 *>(yo + 8 * rg) = q;
                 }
             }

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino(const FwdGeom g, const Wino
     __syncthreads();
     const float *xi = Xs + (size_t)(wave ^ 2) * 1024 + lane;
     const int k = kb * 32 + i;
-    const float bv = bias ? bias[k] : 0.f;
+    const float bv = settled(bias ? bias[k] : 0.f);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int pi = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -467,6 +467,18 @@ constexpr int W2B = MVD_W2B;  // staging loads in flight per thread before the L
 constexpr int W2EH = 6, W2EW = 10, W2EHW = 60;  // halo of the 4 x 4 x 8 tile: 6 x 6 x 10 slots
 __device__ __forceinline__ constexpr int w2_coff(int c) { return (c >> 1) + 5 * (c & 1); }  // slot offset of patch column c
 
+#ifndef MVD_WINO_DBG
+#define MVD_WINO_DBG 0
+#endif
+#if (MVD_WINO_DBG & 64)  // diagnostic build only (tools/stamps_wino.py): s_memtime stamps of one wave per chunk
+__device__ long long g_wino_stamps[64 * 8];
+extern "C" int mvd_debug_wino_stamps(long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_stamps), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : 1;
+}
+#define MVD_WS(K) { if (stamp_on && nst < 60) g_wino_stamps[nst * 8 + (K)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define MVD_WS(K)
+#endif
 __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const WinoTile tg, const float *__restrict__ a1,
                                                       const float *__restrict__ a2, const float *__restrict__ u,
                                                       const float *__restrict__ bias, float *__restrict__ y1,
@@ -522,13 +534,19 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     const bool okA = okw && ihA >= 0 && ihA < g.Hi, okB = okw && ihB >= 0 && ihB < g.Hi;
     v4f *lds_st = reinterpret_cast<v4f *>(Xs + (size_t)(r3 * W2EW + (sx >> 1) + 5 * (sx & 1)) * WXS + part * 4);
 
+    const int k = kb * 32 + i;
     f32x16 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; b++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
 
+#if (MVD_WINO_DBG & 64)
+    const bool stamp_on = item == 300 && wave == 0 && lane == 0;
+    int nst = 0;
+#endif
     for (int cc = 0; cc < nch; cc++) {
+        MVD_WS(0)
         const int c0 = cc * 32;
         const float *src;
         int Cs, cofs;
@@ -542,7 +560,9 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
 #pragma unroll
         for (int b = 0; b < 4; b++)
             wb[0][b] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(uc + b * uq) + ulane);
+        MVD_WS(1)
         __syncthreads();  // every wave is done with the previous chunk's halo
+        MVD_WS(2)
         {
             // byte offsets inside a (n, z) plane; only used when okA / okB (host checks Hi * Wi * Cs * 4 < 2^31)
             const unsigned offA = (unsigned)((ihA * g.Wi + iw) * Cs + cofs + part * 4) << 2;
@@ -569,7 +589,9 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
                 }
             }
         }
+        MVD_WS(3)
         __syncthreads();
+        MVD_WS(4)
         // 12 steps (plane gz, channel quarter e).  The patch of step s + 1 is read from LDS before the MFMAs of step s
         // are issued, so its latency hides behind them: the P[ra] rows go to a second register set (parity e & 1), the
         // P[rb] rows back into the registers the transform of step s has just released.
@@ -625,7 +647,14 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
                 for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vh[b].y, wb[e & 1][b].w, acc[b], 0, 0, 0);
             }
         }
+        MVD_WS(5)
+#if (MVD_WINO_DBG & 64)
+        nst++;
+#endif
     }
+    // the bias, settled before the first store (common.h): the stores of the tile then pipeline instead of running as
+    // sixteen serialised write round trips
+    const float bv = settled(bias ? bias[k] : 0.f);
     // output transform.  Column half in registers, row half across the four waves through LDS.
     f32x16 t0, t1;
 #pragma unroll
@@ -633,7 +662,9 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
         t0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
         t1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
     }
+    MVD_WS(0)
     __syncthreads();  // all MFMA operand reads of the halo are done
+    MVD_WS(1)
     {
         float *xo = Xs + (size_t)wave * 2048 + lane;
 #pragma unroll
@@ -642,27 +673,34 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             xo[1024 + r * 64] = t1[r];
         }
     }
+    MVD_WS(2)
     __syncthreads();
+    MVD_WS(3)
     // wave (yr, yc) = (wave >> 1, wave & 1) finishes output voxel (yr, yc) of each quad from column tile t_yc of
     // position rows {0,1,2} (yr = 0: sum) or {1,2,3} (yr = 1: t[1] - t[2] - t[3]).  Accumulator row r of lane half h is
     // quad q = (r & 3) + 8 * (r >> 2) + 4 * h = (plane r & 3, column 2 * ((r >> 2) & 1) + h, quad row r >> 3): plane,
     // quad row and the column's upper bit are wave-uniform, the lane half moves the output by two voxels along W.
     const int yr = wave >> 1, yc = wave & 1;
     const float *xt = Xs + (size_t)yc * 1024 + lane;
-    const int k = kb * 32 + i;
-    const float bv = bias ? bias[k] : 0.f;
     const int owl = ow0 + yc + 2 * h;                          // + 4 * ((r >> 2) & 1)
     const bool okw0 = owl < g.Wo, okw1 = owl + 4 < g.Wo;
     float ssum = 0.f, ssq = 0.f;  // InstanceNorm statistics of this tile (optional epilogue)
+    // all 48 exchange reads first (unconditional: one LDS latency instead of sixteen behind the store predicates)
+    float vals[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
+                    tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
+        vals[r] = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (g.K2 == 0 || g.K1 == g.K2) {
         // one voxel stride for every lane: per-lane column pointer (once) + a scalar voxel offset per r
         const int Ks = g.K1;
         float *ylane = (k < g.K1 ? y1 + k : y2 + (k - g.K1)) + (size_t)(2 * h) * Ks;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
-                        tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
-            const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
+            const float val = vals[r];
             const int od = od0 + (r & 3), oh = oh0 + 2 * (r >> 3) + yr;   // wave-uniform
             const int owu = ow0 + yc + 4 * ((r >> 2) & 1);                // wave-uniform part of ow
             const size_t uo = ((((size_t)n * g.Dy + od) * g.Hy + oh) * g.Wy + owu) * Ks;
@@ -675,9 +713,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
     } else {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float ta = xt[(size_t)(yr + 0) * 2048 + r * 64], tb = xt[(size_t)(yr + 1) * 2048 + r * 64],
-                        tc = xt[(size_t)(yr + 2) * 2048 + r * 64];
-            const float val = (yr == 0 ? (ta + tb) + tc : (ta - tb) - tc) + bv;
+            const float val = vals[r];
             const int od = od0 + (r & 3), oh = oh0 + 2 * (r >> 3) + yr;
             const int ow = owl + 4 * ((r >> 2) & 1);
             if (od < g.Do && oh < g.Ho && ow < g.Wo) {
@@ -689,6 +725,7 @@ __global__ __launch_bounds__(256, 3) void k_fwd_wino2(const FwdGeom g, const Win
             }
         }
     }
+    MVD_WS(6)
     if (stats != nullptr) {  // block-uniform
         // sum x, sum x^2 over the tile's (up to 128) voxels per output channel, in a fixed order: lane halves, then waves
         ssum += __shfl_xor(ssum, 32, 64);
