@@ -2060,6 +2060,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallc(const WgradGeom g, cons
 // NA / NB: uint4 (8 channels) per thread of the A halo / B tile.  Same split-K / prefetch structure as k_wgrad_mfma.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 
 __device__ inline bf16x8w tr_operand(const unsigned char *p0, const unsigned char *p1) {
@@ -2069,7 +2070,26 @@ __device__ inline bf16x8w tr_operand(const unsigned char *p0, const unsigned cha
     return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int TPW, int NA, int NB, int SH>
+#ifndef MVD_WG16_DBG
+#define MVD_WG16_DBG 0
+#endif
+#if (MVD_WG16_DBG & 64)  // diagnostic build only (tools/stamps_wgrad16.py): s_memtime stamps of one wave per tile
+__device__ long long g_wg16_stamps[64 * 8];
+extern "C" int mvd_debug_wg16_stamps(long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg16_stamps), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : 1;
+}
+#define MVD_WGS(K) { if (stamp_on && nst < 60) g_wg16_stamps[nst * 8 + (K)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define MVD_WGS(K)
+#endif
+// TRI (the plain 27-tap stride-1 gather with 8-voxel tile rows: SH == 1, TPW == 7): the three taps of an x-triple read the
+// same halo row shifted by one voxel, so a wave takes two whole triples (taps 6 w .. 6 w + 5) plus one tap of the ninth
+// triple (24 + w; wave 3's seventh slot stays the ones slot of the bias gradient), fetches the 12-voxel union of a
+// triple with THREE transposing reads instead of six and derives the three A fragments in registers (the odd shift is
+// four v_perm / v_alignbit).  10 + 1 LDS reads per 7 MFMAs instead of 16 + 1, and with 20 instead of 32 operand
+// registers per step the 256-voxel tile can afford the double-buffered fetch it had to drop (its steps ran as
+// table read -> address adds -> operand reads -> MFMAs, one latency chain each: MFMA pipe 40 % busy, PMC round 2).
+template <int TPW, int NA, int NB, int SH, bool TRI = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgTile tg,
                                                     const unsigned short *__restrict__ a1,
                                                     const unsigned short *__restrict__ a2,
@@ -2085,13 +2105,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
     const int split = blockIdx.x;
     const int C = g.C1 + g.C2, K = g.K;
 
+    static_assert(!TRI || (TPW == 7 && SH == 1), "TRI: 27 taps over 4 waves x 7 slots, one dy fragment for all taps");
+    auto tap_of = [&](int j) { return TRI ? (j < 6 ? 6 * wave + j : 24 + wave) : wave + 4 * j; };
     int ta[TPW], tb[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
         ta[j] = tb[j] = 0;
 #pragma unroll
         for (int t = 0; t < 27; t++)
-            if (t == wave + 4 * j && t < g.ntaps) {
+            if (t == tap_of(j) && t < g.ntaps) {
                 ta[j] = tg.toffA[t];
                 tb[j] = tg.toffB[t];
             }
@@ -2122,26 +2144,60 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
     // address per 16-byte load for every tile: ~270 VALU instructions per tile and wave next to 56 MFMAs.  Interior
     // tiles (no halo voxel outside the volume; the majority) now load from scalar base + lane offset with no bounds
     // logic; border tiles test the precomputed coordinates.
-    int relA[NA], czA[NA], relB[NB], czB[NB];
-#pragma unroll
-    for (int u = 0; u < NA; u++) {
+    // (the packed halo coordinates the border tiles test are recomputed there: kept in registers they cost NA + NB of
+    // the 256 for the whole kernel)
+    unsigned relA[NA], relB[NB];  // BYTE offsets (< 2^31, host-checked tile extents): scalar base + 32-bit lane offset loads
+    auto coordsA = [&](int u, int tid) {
         const int idx = u * 256 + tid;
         const int slot = idx < na ? (idx >> 2) : 0;
         const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
         const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
-        relA[u] = ((ez * g.Hi + ey) * g.Wi + ex) * Cs + part * 8;
-        czA[u] = idx < na ? ((ez << 16) | (ey << 8) | ex) : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < NB; u++) {
+        return idx < na ? ((ez << 16) | (ey << 8) | ex) : -1;
+    };
+    auto coordsB = [&](int u, int tid) {
         const int idx = u * 256 + tid;
         const int slot = idx < nb ? (idx >> 2) : 0;
         const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
         const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
-        relB[u] = ((ez * g.Hb + ey) * g.Wb + ex) * K + part * 8;
-        czB[u] = idx < nb ? ((ez << 16) | (ey << 8) | ex) : -1;
+        return idx < nb ? ((ez << 16) | (ey << 8) | ex) : -1;
+    };
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+        const int c = coordsA(u, tid);
+        relA[u] = (unsigned)((((c >> 16) * g.Hi + ((c >> 8) & 255)) * g.Wi + (c & 255)) * Cs + part * 8) * 2u;
+        if (c < 0) relA[u] = part * 16;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int c = coordsB(u, tid);
+        relB[u] = (unsigned)((((c >> 16) * g.Hb + ((c >> 8) & 255)) * g.Wb + (c & 255)) * K + part * 8) * 2u;
+        if (c < 0) relB[u] = part * 16;
     }
     const int EAd = (tg.nslotsA / EAhw), EBd = (tg.nslotsB / EBhw);  // halo extents along D
+    // 16 bytes at wave-uniform base + 32-bit lane byte offset.  The opaque copy keeps the zero-extension next to the load,
+    // which then takes the scalar-base + 32-bit-offset form; kept as 64-bit element offsets the NA + NB offsets cost
+    // twice the registers and a 64-bit add per load.
+    auto ld16 = [](const unsigned short *base, unsigned off) {
+        asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(base) + off);
+    };
+    // tile -> halo bases; true when no halo voxel of either operand lies outside its volume (block-uniform)
+    int nza = 0, nya = 0, nxa = 0, nzb = 0, nyb = 0, nxb = 0;  // first halo voxel of the tile tile_bases() last decoded
+    auto tile_bases = [&](int tile, const unsigned short *&baseA, const unsigned short *&baseB) {
+        unsigned r_ = (unsigned)tile;
+        const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+        const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+        const int td_ = (int)(r_ % (unsigned)tg.ntd);
+        const int n = (int)(r_ / (unsigned)tg.ntd);
+        const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
+        const int za = od0 * g.sa[0] + tg.minA[0], ya = oh0 * g.sa[1] + tg.minA[1], xa = ow0 * g.sa[2] + tg.minA[2];
+        const int zb = od0 * g.sb[0] + tg.minB[0], yb = oh0 * g.sb[1] + tg.minB[1], xb = ow0 * g.sb[2] + tg.minB[2];
+        nza = za; nya = ya; nxa = xa; nzb = zb; nyb = yb; nxb = xb;
+        baseA = asrc + ((((long)n * g.Di + za) * g.Hi + ya) * g.Wi + xa) * (long)Cs + cofs;
+        baseB = b + ((((long)n * g.Db + zb) * g.Hb + yb) * g.Wb + xb) * (long)K + k0;
+        return za >= 0 && za + EAd <= g.Di && ya >= 0 && ya + tg.EAh <= g.Hi && xa >= 0 && xa + tg.EAw <= g.Wi && zb >= 0 &&
+               zb + EBd <= g.Db && yb >= 0 && yb + tg.EBh <= g.Hb && xb >= 0 && xb + tg.EBw <= g.Wb;
+    };
     auto load_tile = [&](int tile) {
         unsigned r_ = (unsigned)tile;
         const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
@@ -2149,21 +2205,23 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
         const int td_ = (int)(r_ % (unsigned)tg.ntd);
         const int n = (int)(r_ / (unsigned)tg.ntd);
         const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
+        int tid_here = tid;  // opaque copy: keeps the border tiles' coordinate decode inside this call (hoisted out of
+        asm volatile("" : "+v"(tid_here));  // the tile loop it would sit in NA + NB registers again)
         {
             const int z0 = od0 * g.sa[0] + tg.minA[0], y0 = oh0 * g.sa[1] + tg.minA[1], x0 = ow0 * g.sa[2] + tg.minA[2];
             const bool interior = z0 >= 0 && z0 + EAd <= g.Di && y0 >= 0 && y0 + tg.EAh <= g.Hi && x0 >= 0 && x0 + tg.EAw <= g.Wi;
             const unsigned short *base = asrc + ((((long)n * g.Di + z0) * g.Hi + y0) * g.Wi + x0) * (long)Cs + cofs;
             if (interior) {  // block-uniform
 #pragma unroll
-                for (int u = 0; u < NA; u++) ra[u] = *reinterpret_cast<const uint4 *>(base + relA[u]);
+                for (int u = 0; u < NA; u++) ra[u] = ld16(base, relA[u]);
             } else {
 #pragma unroll
                 for (int u = 0; u < NA; u++) {
-                    const int c = czA[u];
+                    const int c = coordsA(u, tid_here);
                     const int id = z0 + (c >> 16), ih = y0 + ((c >> 8) & 255), iw = x0 + (c & 255);
                     ra[u] = make_uint4(0u, 0u, 0u, 0u);
                     if (c >= 0 && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
-                        ra[u] = *reinterpret_cast<const uint4 *>(base + relA[u]);
+                        ra[u] = ld16(base, relA[u]);
                 }
             }
         }
@@ -2173,15 +2231,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
             const unsigned short *base = b + ((((long)n * g.Db + z0) * g.Hb + y0) * g.Wb + x0) * (long)K + k0;
             if (interior) {
 #pragma unroll
-                for (int u = 0; u < NB; u++) rb[u] = *reinterpret_cast<const uint4 *>(base + relB[u]);
+                for (int u = 0; u < NB; u++) rb[u] = ld16(base, relB[u]);
             } else {
 #pragma unroll
                 for (int u = 0; u < NB; u++) {
-                    const int c = czB[u];
+                    const int c = coordsB(u, tid_here);
                     const int id = z0 + (c >> 16), ih = y0 + ((c >> 8) & 255), iw = x0 + (c & 255);
                     rb[u] = make_uint4(0u, 0u, 0u, 0u);
                     if (c >= 0 && id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb)
-                        rb[u] = *reinterpret_cast<const uint4 *>(base + relB[u]);
+                        rb[u] = ld16(base, relB[u]);
                 }
             }
         }
@@ -2221,24 +2279,57 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
         }
         steptab[e] = make_int4(t4[0], t4[1], t4[2], t4[3]);
     }
+    if (TRI && tid < 16) reinterpret_cast<unsigned *>(lds8 + (size_t)(NA + NB) * 4096 + (size_t)TV * 64)[tid] = 0x3f803f80u;  // bf16 ones
 
     // Bias gradient (SH == 1: every tap reads the same dy fragment): with 27 taps over 4 waves x 7 slots the last slot of
     // wave 3 is idle -- its A operand becomes a block of ones, so its accumulator rows are the column sums of dy over
     // the voxels of this workgroup's tiles (fp32 accumulation of bf16 values, like the weight gradient itself).  Replaces
     // a separate pass over dy (k_colsum4) per layer.
-    const bool ones_slot = SH == 1 && pbias != nullptr && wave + 4 * (TPW - 1) >= g.ntaps;
+    const bool ones_slot = SH == 1 && pbias != nullptr && tap_of(TPW - 1) >= g.ntaps;
     bf16x8w ones;
 #pragma unroll
     for (int e = 0; e < 8; e++) ones[e] = (__bf16)1.0f;
 
+#if (MVD_WG16_DBG & 64)
+    const bool stamp_on = blockIdx.x == 100 && blockIdx.y == 0 && wave == 0 && lane == 0;
+    int nst = 0;
+#endif
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
+    if (TRI && tg.dbg > 0) {
+        // experiment (MVD_WG16_DELAY): the second workgroup of a CU starts half a tile period late
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((lin >> 8) & 1)
+            for (int d = 0; d < tg.dbg; d++) __builtin_amdgcn_s_sleep(16);
+    }
     while (tile < tg.ntiles) {
+        MVD_WGS(0)
         __syncthreads();
+        MVD_WGS(1)
         store_tile();
+        MVD_WGS(2)
         __syncthreads();
+        MVD_WGS(3)
         const int next = tile + tg.nsplit;
-        if (next < tg.ntiles) load_tile(next);
+        // TRI: the next tile's global loads are issued one or two per MFMA step inside the step loop.  Issued in one
+        // burst they cost the burst's time at the L1's 64 B/clk -- 57 KB per tile and workgroup, 2-3 kilocycles of the
+        // 11 a tile took with nothing else of this wave in flight.  They are BUFFER loads and unconditional: a lane
+        // whose halo voxel lies outside the volume (border tiles) passes an out-of-range offset and gets zeros, and
+        // after the last tile the descriptors have zero records (no traffic).  Any branch around a load makes the
+        // compiler guard the following loads with s_waitcnt vmcnt(0), one memory latency per step (measured: 14 instead
+        // of 6.4 kilocycles per tile).
+        bool nint = true;
+        __amdgpu_buffer_rsrc_t rA, rB;
+        if (TRI) {
+            const unsigned short *nbA = a1, *nbB = b;
+            const bool more = next < tg.ntiles;
+            if (more) nint = tile_bases(next, nbA, nbB);
+            rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(nbA), 0, more ? 0x7fffffff : 0, 0x00020000);
+            rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(nbB), 0, more ? 0x7fffffff : 0, 0x00020000);
+        } else if (next < tg.ntiles) {
+            load_tile(next);
+        }
+        MVD_WGS(4)
         // operands of step s+1 are fetched (step-table read, address adds, transposing reads) before the MFMAs of step s
         // are issued, into the other half of a double buffer: un-pipelined, every step exposed two LDS round trips
         // (table, then operands: s_waitcnt lgkmcnt(0) twice) and 16 address adds in front of its 7 MFMAs
@@ -2255,7 +2346,82 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
             for (int j = 0; j < NBV; j++) bv[buf][j] = tr_operand(Bs + sb_[0] + boff[j], Bs + sb_[1] + boff[j]);
         };
         constexpr bool PIPE = NA < 10;  // (the 256-voxel tile has no registers left for the second operand set)
-        if (PIPE) {
+        if constexpr (TRI) {
+            // Straight-line code (the step count is a compile-time constant, no wave-dependent branch): the waits the
+            // compiler places are then exact counts, i.e. the MFMAs of step s wait for the reads of step s and not
+            // for the reads of step s + 1 issued just before them.  (With the run-time loop and the ones-slot branch
+            // around the single-tap reads every second step sat behind s_waitcnt lgkmcnt(0): 75 instead of 32 pipe
+            // cycles per MFMA and wave in the s_memtime stamps of tools/stamps_wgrad16.py.)
+            // raw[buf]: the union reads of the two triples (3 x 4 voxels each), the single tap (2 x 4) and dy (2 x 4)
+            constexpr int NSTEP = (NA == 10 ? 256 : 128) / 16;  // == TV / 16 (host-checked)
+            s16x4 rt[2][2][3], rs[2][2], rbv[2][2];
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            auto trd = [&](const unsigned char *p_) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p_); };
+            // wave 3's seventh slot (bias gradient): every lane reads the same 8 bytes of bf16 ones behind the step table
+            const unsigned char *ones_row = lds8 + (size_t)(NA + NB) * 4096 + (size_t)NSTEP * 1024;
+            auto fetch3 = [&](const int4 t4, int buf) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    rt[buf][q][0] = trd(As + t4.x + aoff[3 * q]);        // voxels x-1 .. x+2 of the row (tap tx = -1 base)
+                    rt[buf][q][1] = trd(As + t4.y + aoff[3 * q]);        // x+3 .. x+6
+                    rt[buf][q][2] = trd(As + t4.y + aoff[3 * q] + 256);  // x+7 .. x+10 (the last two are never used)
+                }
+                rs[buf][0] = trd(ones_slot ? ones_row : As + t4.x + aoff[6]);
+                rs[buf][1] = trd(ones_slot ? ones_row : As + t4.y + aoff[6]);
+                rbv[buf][0] = trd(Bs + t4.z + boff[0]);
+                rbv[buf][1] = trd(Bs + t4.w + boff[0]);
+            };
+            auto step3 = [&](int buf) {
+                const bf16x8w bfrag = __builtin_bit_cast(bf16x8w, __builtin_shufflevector(rbv[buf][0], rbv[buf][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const s16x8 a01 = __builtin_shufflevector(rt[buf][q][0], rt[buf][q][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s16x8 a12 = __builtin_shufflevector(rt[buf][q][1], rt[buf][q][2], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s16x8 f1 = __builtin_shufflevector(a01, a12, 1, 2, 3, 4, 5, 6, 7, 12);
+                    const s16x8 f2 = __builtin_shufflevector(a01, a12, 2, 3, 4, 5, 6, 7, 12, 13);
+                    acc[3 * q + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8w, a01), bfrag, acc[3 * q + 0], 0, 0, 0);
+                    acc[3 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8w, f1), bfrag, acc[3 * q + 1], 0, 0, 0);
+                    acc[3 * q + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8w, f2), bfrag, acc[3 * q + 2], 0, 0, 0);
+                }
+                const bf16x8w sfrag = __builtin_bit_cast(bf16x8w, __builtin_shufflevector(rs[buf][0], rs[buf][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag, bfrag, acc[6], 0, 0, 0);
+            };
+            int4 t_nxt = steptab[64 + lane];  // the table row is read two steps ahead of its MFMAs
+            fetch3(steptab[lane], 0);
+#pragma unroll
+            for (int st = 0; st < NSTEP; st++) {
+                if (st + 1 < NSTEP) {
+                    const int4 t_use = t_nxt;
+                    if (st + 2 < NSTEP) t_nxt = steptab[(st + 2) * 64 + lane];
+                    fetch3(t_use, (st + 1) & 1);
+                }
+                {
+                    constexpr int LPS = (NA + NB + NSTEP - 1) / NSTEP;  // loads per step
+#pragma unroll
+                    for (int u = st * LPS; u < (st + 1) * LPS && u < NA + NB; u++) {
+                        const bool isA = u < NA;
+                        const int ua = isA ? u : 0, ub = isA ? 0 : u - NA;
+                        unsigned o = isA ? relA[ua] : relB[ub];
+                        if (!nint) {  // block-uniform; VALU only inside
+                            int tid_here = tid;
+                            asm volatile("" : "+v"(tid_here));
+                            const int c = isA ? coordsA(ua, tid_here) : coordsB(ub, tid_here);
+                            const int id = (isA ? nza : nzb) + (c >> 16), ih = (isA ? nya : nyb) + ((c >> 8) & 255),
+                                      iw = (isA ? nxa : nxb) + (c & 255);
+                            const bool ok = c >= 0 && id >= 0 && id < (isA ? g.Di : g.Db) && ih >= 0 && ih < (isA ? g.Hi : g.Hb) &&
+                                            iw >= 0 && iw < (isA ? g.Wi : g.Wb);
+                            o = ok ? o : 0xffffffffu;
+                        }
+                        const u32x4w q4 = __builtin_amdgcn_raw_buffer_load_b128(isA ? rA : rB, (int)o, 0, 0);
+                        if (isA) ra[ua] = make_uint4(q4[0], q4[1], q4[2], q4[3]);
+                        else rb[ub] = make_uint4(q4[0], q4[1], q4[2], q4[3]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the reads to just before their use)
+                step3(st & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (PIPE) {
             fetch(0, 0);
             for (int s16 = 0; s16 < TV; s16 += 32) {  // TV is a multiple of 16
 #pragma unroll
@@ -2277,11 +2443,15 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0][SH == 2 ? 0 : j], bv[0][SH == 1 ? 0 : j], acc[j], 0, 0, 0);
             }
         }
+        MVD_WGS(5)
+#if (MVD_WG16_DBG & 64)
+        nst++;
+#endif
         tile = next;
     }
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
-        const int t = wave + 4 * j;
+        const int t = tap_of(j);
         if (t < g.ntaps) {
             float *po = partial + ((size_t)split * g.ntaps + t) * C * K;
 #pragma unroll
@@ -2499,9 +2669,23 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         if (dbias && dbias_done && (cfg == 0 || cfg == 2) && sameB && tpw == 7 && g.ntaps < 28 &&
             need_ws + (size_t)tg.nsplit * g.K * sizeof(float) <= ws_bytes)
             pbias16 = partial + need_ws / sizeof(float);
-#define WG16(TPW, NA, NB, SH)                                                                                              \
-    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH>), grid, dim3(256), (size_t)(NA + NB) * 4096 + (size_t)(tg.TD * tg.TH * tg.TW) * 64, \
-                       s, g, tg, h1, h2, hb, partial, (TPW) == 7 && (SH) == 1 ? pbias16 : nullptr)
+        // TRI: the x-triples of the plain 27-tap stride-1 gather share their halo-row reads (see k_wgrad16)
+        static int tri_env = -1;
+        if (tri_env < 0) tri_env = getenv("MVD_WGRAD16_TRI") ? atoi(getenv("MVD_WGRAD16_TRI")) : 1;
+        static int delay_env = -1;
+        if (delay_env < 0) delay_env = getenv("MVD_WG16_DELAY") ? atoi(getenv("MVD_WG16_DELAY")) : 0;
+        tg.dbg = delay_env;
+        bool tri = tri_env != 0 && sameB && tpw == 7 && g.ntaps == 27 && tg.TW == 8 && g.sa[2] == 1 &&
+                   tg.TD * tg.TH * tg.TW == (cfg == 2 ? 256 : 128);
+        for (int t = 0; t < 27 && tri; t++) tri = tg.toffA[t] == tg.toffA[t - t % 3] + t % 3;
+        // (the third read of a triple runs two slots past its 10-slot halo row: inside the A image except for the very
+        // last row, where it reads the first bytes of the B image -- both inside the allocation, values never used)
+#define WG16T(TPW, NA, NB, SH, TRI)                                                                                          \
+    hipLaunchKernelGGL((k_wgrad16<TPW, NA, NB, SH, TRI>), grid, dim3(256),                                                  \
+                       (size_t)(NA + NB) * 4096 + (size_t)(tg.TD * tg.TH * tg.TW) * 64 + ((TRI) ? 64 : 0), s, g, tg, h1, h2, \
+                       hb, partial,                                                                                          \
+                       (TPW) == 7 && (SH) == 1 ? pbias16 : nullptr)
+#define WG16(TPW, NA, NB, SH) WG16T(TPW, NA, NB, SH, false)
 #define WG16_TPW(NA, NB, SH)                  \
     {                                         \
         if (tpw <= 1) WG16(1, NA, NB, SH);    \
@@ -2519,9 +2703,23 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                 }
                 cfgd_big = true;
             }
-            WG16(7, 10, 4, 1);
+            if (tri) {
+                static bool cfgd_tri = false;
+                if (!cfgd_tri) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad16<7, 10, 4, 1, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) {
+                        set_error("conv wgrad (bf16 mfma): cannot raise the dynamic LDS limit");
+                        return 1;
+                    }
+                    cfgd_tri = true;
+                }
+                WG16T(7, 10, 4, 1, true);
+            } else {
+                WG16(7, 10, 4, 1);
+            }
         } else if (cfg == 0) {
-            if (sameB) WG16_TPW(7, 2, 1)
+            if (sameB && tri) WG16T(7, 7, 2, 1, true);
+            else if (sameB) WG16_TPW(7, 2, 1)
             else WG16_TPW(7, 2, 0)
         } else {
             if (sameA) WG16_TPW(1, 8, 2)
@@ -2529,6 +2727,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         }
 #undef WG16_TPW
 #undef WG16
+#undef WG16T
         if (check_launch("conv wgrad (bf16 mfma)")) return 1;
         const long per16 = (long)g.ntaps * C * g.K;
         const int wblocks = (int)cdiv(per16, 64);
