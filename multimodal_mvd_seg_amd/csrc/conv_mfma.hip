@@ -1515,6 +1515,18 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_wino(const WgradGeom g, const 
 // other's barrier / LDS waits).  TPB = threads per workgroup (staging loops).
 // GZ0 / NGZ: the wave owns filter planes GZ0 .. GZ0+NGZ-1 (3 planes by default; the twelve-wave variant gives each wave
 // one plane and all four columns: 64 accumulator registers, three waves per SIMD).
+#ifndef MVD_WG16_DBG
+#define MVD_WG16_DBG 0
+#endif
+#if (MVD_WG16_DBG & 64)  // diagnostic build only (tools/stamps_wgrad16.py): s_memtime stamps of one wave per tile
+__device__ long long g_wg16_stamps[64 * 8];
+extern "C" int mvd_debug_wg16_stamps(long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg16_stamps), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : 1;
+}
+#define MVD_WGS(K) { if (stamp_on && nst < 60) g_wg16_stamps[nst * 8 + (K)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define MVD_WGS(K)
+#endif
 template <int A, int B0, int NBW, int TPB, int NA, int NB, int GZ0 = 0, int NGZ = 3>
 __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTile &tg, const float *__restrict__ a1,
                                                  const float *__restrict__ a2, const float *__restrict__ b,
@@ -1654,14 +1666,26 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
     // quads it fetches for E): per-lane partial sums, reduced over lanes halves / splits by k_dbias_reduce
     const float bflag = (A == 0 && B0 == 0 && GZ0 == 0 && pbias != nullptr && cb == 0) ? 1.f : 0.f;
     float bsum = 0.f;
+#if (MVD_WG16_DBG & 64)
+    const bool stamp_on = (MVD_WG16_DBG & 128) && blockIdx.x == 100 && blockIdx.y == 0 && A == 0 && GZ0 == 0 && B0 == 0 && lane == 0;
+    int nst = 0;
+#endif
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
     while (tile < tg.ntiles) {
+        MVD_WGS(0)
         __syncthreads();
+        MVD_WGS(1)
         store_tile();
+        MVD_WGS(2)
         __syncthreads();
+        MVD_WGS(3)
         const int next = tile + tg.nsplit;
+        // (issued here, with every wave of the workgroup doing it at the same time and the MFMA pipe idle: 2 k of a 20 k
+        // ticks tile in the s_memtime stamps of tools/stamps_wgrad_wino.py.  Issuing them one quad row into the steps,
+        // where the waves are skewed and the others' MFMAs would cover it, measured 3-4 % SLOWER on every layer shape.)
         if (next < tg.ntiles) load_tile(next);
+        MVD_WGS(4)
         // window of the first quad: columns 0..3 of quad row 0, and its dy quad
         {
             float e[4];
@@ -1747,6 +1771,10 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        MVD_WGS(5)
+#if (MVD_WG16_DBG & 64)
+        nst++;
+#endif
         tile = next;
     }
     // partial[split][gz][a][b][c][k]; D layout: col = lane&31 -> k, row -> c
@@ -2070,18 +2098,6 @@ __device__ inline bf16x8w tr_operand(const unsigned char *p0, const unsigned cha
     return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-#ifndef MVD_WG16_DBG
-#define MVD_WG16_DBG 0
-#endif
-#if (MVD_WG16_DBG & 64)  // diagnostic build only (tools/stamps_wgrad16.py): s_memtime stamps of one wave per tile
-__device__ long long g_wg16_stamps[64 * 8];
-extern "C" int mvd_debug_wg16_stamps(long long *host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg16_stamps), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : 1;
-}
-#define MVD_WGS(K) { if (stamp_on && nst < 60) g_wg16_stamps[nst * 8 + (K)] = __builtin_amdgcn_s_memtime(); }
-#else
-#define MVD_WGS(K)
-#endif
 // TRI (the plain 27-tap stride-1 gather with 8-voxel tile rows: SH == 1, TPW == 7): the three taps of an x-triple read the
 // same halo row shifted by one voxel, so a wave takes two whole triples (taps 6 w .. 6 w + 5) plus one tap of the ninth
 // triple (24 + w; wave 3's seventh slot stays the ones slot of the bias gradient), fetches the 12-voxel union of a
@@ -2291,7 +2307,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
     for (int e = 0; e < 8; e++) ones[e] = (__bf16)1.0f;
 
 #if (MVD_WG16_DBG & 64)
-    const bool stamp_on = blockIdx.x == 100 && blockIdx.y == 0 && wave == 0 && lane == 0;
+    const bool stamp_on = !(MVD_WG16_DBG & 128) && blockIdx.x == 100 && blockIdx.y == 0 && wave == 0 && lane == 0;
     int nst = 0;
 #endif
     int tile = split;
