@@ -1527,7 +1527,10 @@ extern "C" int mvd_debug_wg16_stamps(long long *host_out) {
 #else
 #define MVD_WGS(K)
 #endif
-template <int A, int B0, int NBW, int TPB, int NA, int NB, int GZ0 = 0, int NGZ = 3>
+// DB: two LDS images (A 4 x 10 x 10 slots + B 2 x 8 x 8 slots, 67 584 bytes each, allocated exactly): a wave writes the
+// next tile into the other image as soon as its own steps are done -- under the MFMAs of the SIMD's younger waves -- and
+// the tile loop has ONE barrier per tile instead of barrier / write / barrier with the MFMA pipe idle.
+template <int A, int B0, int NBW, int TPB, int NA, int NB, int GZ0 = 0, int NGZ = 3, bool DB = false>
 __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTile &tg, const float *__restrict__ a1,
                                                  const float *__restrict__ a2, const float *__restrict__ b,
                                                  float *__restrict__ partial, float *__restrict__ pbias, float *As,
@@ -1628,11 +1631,17 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
             }
         }
     };
-    auto store_tile = [&]() {
+    constexpr int DBUF = (4 * EAH * EAW + 2 * EBH * EBW) * 128;  // bytes of one image pair (DB)
+    auto store_tile = [&](int par) {
+        float *Ad = As + (DB ? par * (DBUF / 4) : 0), *Bd = Bs + (DB ? par * (DBUF / 4) : 0);
 #pragma unroll
-        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * TPB + tid) * 4) = ra[u];
+        for (int u = 0; u < NA; u++)
+            if (!DB || (u + 1) * TPB <= 4 * EAH * EAW * 8 || u * TPB + tid < na)  // (exact allocation: no slack to write into)
+                *reinterpret_cast<float4 *>(Ad + (size_t)(u * TPB + tid) * 4) = ra[u];
 #pragma unroll
-        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * TPB + tid) * 4) = rb[u];
+        for (int u = 0; u < NB; u++)
+            if (!DB || (u + 1) * TPB <= 2 * EBH * EBW * 8 || u * TPB + tid < nb)
+                *reinterpret_cast<float4 *>(Bd + (size_t)(u * TPB + tid) * 4) = rb[u];
     };
 
     const char *Ab = reinterpret_cast<const char *>(As), *Bb = reinterpret_cast<const char *>(Bs);
@@ -1672,13 +1681,20 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
 #endif
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
+    int par = 0;
+    if (DB) {
+        if (tile < tg.ntiles) store_tile(0);
+        __syncthreads();
+    }
     while (tile < tg.ntiles) {
         MVD_WGS(0)
-        __syncthreads();
-        MVD_WGS(1)
-        store_tile();
-        MVD_WGS(2)
-        __syncthreads();
+        if (!DB) {
+            __syncthreads();
+            MVD_WGS(1)
+            store_tile(0);
+            MVD_WGS(2)
+            __syncthreads();
+        }
         MVD_WGS(3)
         const int next = tile + tg.nsplit;
         // (issued here, with every wave of the workgroup doing it at the same time and the MFMA pipe idle: 2 k of a 20 k
@@ -1772,6 +1788,15 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
             }
         }
         MVD_WGS(5)
+        if (DB) {
+            if (next < tg.ntiles) store_tile(par ^ 1);
+            MVD_WGS(6)
+            __syncthreads();
+            MVD_WGS(7)
+            par ^= 1;
+            Ab = reinterpret_cast<const char *>(As) + par * DBUF;
+            Bb = reinterpret_cast<const char *>(Bs) + par * DBUF;
+        }
 #if (MVD_WG16_DBG & 64)
         nst++;
 #endif
@@ -1851,15 +1876,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad_wino2w8(const WgradGeom g, con
 
 // twelve-wave variant: wave w owns position row w & 3 and filter plane w >> 2 with all four columns (4 accumulator tiles):
 // three waves per SIMD; NA12 / NB12 = float4 per thread of the same LDS tiles staged by 768 threads
-template <int NA12, int NB12>
+template <int NA12, int NB12, bool DB12 = false>
 __global__ __launch_bounds__(768, 1) void k_wgrad_wino2w12(const WgradGeom g, const WgTile tg, const float *__restrict__ a1,
                                                            const float *__restrict__ a2, const float *__restrict__ b,
                                                            float *__restrict__ partial, float *__restrict__ pbias) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;
-    float *Bs = lds + (size_t)NA12 * 3072;  // A region: NA12 float4 per thread x 768 threads
+    float *Bs = lds + (DB12 ? (size_t)4 * 10 * 10 * 32 : (size_t)NA12 * 3072);  // A: exact (DB) / NA12 float4 x 768 threads
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#define MVD_W12(AA, GZ) wgrad_wino2_body<AA, 0, 4, 768, NA12, NB12, GZ, 1>(g, tg, a1, a2, b, partial, pbias, As, Bs)
+#define MVD_W12(AA, GZ) wgrad_wino2_body<AA, 0, 4, 768, NA12, NB12, GZ, 1, DB12>(g, tg, a1, a2, b, partial, pbias, As, Bs)
     switch (wave) {
         case 0: MVD_W12(0, 0); break;
         case 1: MVD_W12(1, 0); break;
@@ -2775,7 +2800,10 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                 float *pbias = (dbias && dbias_done) ? partial + need_m2 / sizeof(float) : nullptr;
                 // MVD_WGRAD_W8: 12 (default) = twelve waves (one plane per wave, 3 per SIMD), 1 = eight waves, 0 = four waves
                 static const int w8 = getenv("MVD_WGRAD_W8") ? atoi(getenv("MVD_WGRAD_W8")) : 12;
-                auto kern2 = w8 == 12 ? k_wgrad_wino2w12<5, 2> : (w8 ? k_wgrad_wino2w8<7, 2> : k_wgrad_wino2<13, 4>);
+                // MVD_WGRAD_DB=0: single LDS image (barrier / write / barrier per tile)
+                static const int db12 = getenv("MVD_WGRAD_DB") ? atoi(getenv("MVD_WGRAD_DB")) : 1;
+                auto kern2 = w8 == 12 ? (db12 ? k_wgrad_wino2w12<5, 2, true> : k_wgrad_wino2w12<5, 2, false>)
+                                      : (w8 ? k_wgrad_wino2w8<7, 2> : k_wgrad_wino2<13, 4>);
                 static bool cfgd_w2 = false;
                 if (!cfgd_w2) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2786,7 +2814,8 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                     cfgd_w2 = true;
                 }
                 hipLaunchKernelGGL(kern2, grid, dim3(w8 == 12 ? 768 : (w8 ? 512 : 256)),
-                                   w8 == 12 ? (size_t)(5 + 2) * 12288 : (w8 ? (size_t)(7 + 2) * 8192 : (size_t)(13 + 4) * 4096), s, g,
+                                   w8 == 12 ? (db12 ? (size_t)2 * (4 * 100 + 2 * 64) * 128 : (size_t)(5 + 2) * 12288)
+                                            : (w8 ? (size_t)(7 + 2) * 8192 : (size_t)(13 + 4) * 4096), s, g,
                                    tg, a1, a2, b, partial, pbias);
                 if (check_launch("conv wgrad (winograd 2-D)")) return 1;
                 if (pbias) {

@@ -22,10 +22,20 @@ buf = (ctypes.c_longlong * 512)()
 lib.mvd_debug_wg16_stamps.restype = ctypes.c_int
 assert lib.mvd_debug_wg16_stamps(buf) == 0
 st = [list(buf[i * 8:(i + 1) * 8]) for i in range(60)]
-print("tile  +barrier +lds-write +barrier +load-issue +steps  | tile period   [ticks]")
-for t in range(1, 60):
-    r = st[t]
-    if r[0] == 0:
-        break
-    if t % 4 == 0:
-        print(f"{t:4d} {r[1]-r[0]:8d} {r[2]-r[1]:10d} {r[3]-r[2]:8d} {r[4]-r[3]:11d} {r[5]-r[4]:7d}  | {r[0]-st[t-1][0]:8d}")
+db = st[1][6] != 0  # two LDS images (default): [3] loop top, [4] next tile's loads issued, [5] steps, [6] next tile written, [7] barrier
+if db:
+    print("tile  +load-issue  +steps  +lds-write  +barrier  | tile period   [ticks]")
+    for t in range(1, 60):
+        r = st[t]
+        if r[0] == 0:
+            break
+        if t % 4 == 0:
+            print(f"{t:4d} {r[4]-r[3]:11d} {r[5]-r[4]:7d} {r[6]-r[5]:11d} {r[7]-r[6]:9d}  | {r[0]-st[t-1][0]:8d}")
+else:
+    print("tile  +barrier +lds-write +barrier +load-issue +steps  | tile period   [ticks]")
+    for t in range(1, 60):
+        r = st[t]
+        if r[0] == 0:
+            break
+        if t % 4 == 0:
+            print(f"{t:4d} {r[1]-r[0]:8d} {r[2]-r[1]:10d} {r[3]-r[2]:8d} {r[4]-r[3]:11d} {r[5]-r[4]:7d}  | {r[0]-st[t-1][0]:8d}")
