@@ -13,6 +13,7 @@
 //   spatial tiles (split-K), staging the A halo [slots][32 c] and B tile [slots][32 k] in LDS, and writes fp32 partials;
 //   a fixed-order second stage sums the splits in fp64 and emits the torch weight layout (deterministic, no atomics).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_geom.h"
@@ -1515,6 +1516,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_wino(const WgradGeom g, const 
 // other's barrier / LDS waits).  TPB = threads per workgroup (staging loops).
 // GZ0 / NGZ: the wave owns filter planes GZ0 .. GZ0+NGZ-1 (3 planes by default; the twelve-wave variant gives each wave
 // one plane and all four columns: 64 accumulator registers, three waves per SIMD).
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 #ifndef MVD_WG16_DBG
 #define MVD_WG16_DBG 0
 #endif
@@ -1697,10 +1699,50 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
         }
         MVD_WGS(3)
         const int next = tile + tg.nsplit;
-        // (issued here, with every wave of the workgroup doing it at the same time and the MFMA pipe idle: 2 k of a 20 k
-        // ticks tile in the s_memtime stamps of tools/stamps_wgrad_wino.py.  Issuing them one quad row into the steps,
-        // where the waves are skewed and the others' MFMAs would cover it, measured 3-4 % SLOWER on every layer shape.)
-        if (next < tg.ntiles) load_tile(next);
+        // Single image: the next tile's loads are issued here, every wave of the workgroup at the same time with the MFMA
+        // pipe idle (2 k of a 20 k ticks tile, tools/stamps_wgrad_wino.py); the same predicated loads one quad row into
+        // the steps measured 3-4 % SLOWER (the branches around them cost the pipelined LDS reads their counted waits).
+        // DB: unconditional BUFFER loads behind the MFMAs of the first quad row (issue_load): a lane whose halo voxel is
+        // outside the volume passes an out-of-range offset and gets zeros, after the last tile the descriptors have
+        // zero records.
+        bool nintA = true, nintB = true;
+        int nz0 = 0, ny0 = 0, nx0 = 0;
+        __amdgpu_buffer_rsrc_t rA, rB;
+        if (DB) {
+            const bool more = next < tg.ntiles;
+            unsigned r_ = (unsigned)(more ? next : 0);
+            const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+            const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+            const int td_ = (int)(r_ % (unsigned)tg.ntd);
+            const int n = (int)(r_ / (unsigned)tg.ntd);
+            nz0 = td_ * 2; ny0 = th_ * 8; nx0 = tw_ * 8;  // first output voxel; the A halo starts one voxel before it
+            nintA = nz0 >= 1 && ny0 >= 1 && nx0 >= 1 && nz0 + 3 <= g.Di && ny0 - 1 + EAH <= g.Hi && nx0 - 1 + EAW <= g.Wi;
+            nintB = nz0 + 2 <= g.Db && ny0 + EBH <= g.Hb && nx0 + EBW <= g.Wb;
+            const float *baseA = asrc + ((((long)n * g.Di + (nz0 - 1)) * g.Hi + (ny0 - 1)) * g.Wi + (nx0 - 1)) * (long)Cs;
+            const float *baseB = b + ((((long)n * g.Db + nz0) * g.Hb + ny0) * g.Wb + nx0) * (long)K;
+            rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(baseA), 0, more ? 0x7fffffff : 0, 0x00020000);
+            rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(baseB), 0, more ? 0x7fffffff : 0, 0x00020000);
+        } else if (next < tg.ntiles) {
+            load_tile(next);
+        }
+        auto issue_load = [&](int u) {
+            if (u >= NA + NB) return;
+            const bool isA = u < NA;
+            const int ua = isA ? u : 0, ub = isA ? 0 : u - NA;
+            const int cz = isA ? cza[ua] : czb[ub];
+            unsigned o = cz >= 0 ? (unsigned)(isA ? rela[ua] : relb[ub]) * 4u : 0xffffffffu;
+            if (isA ? !nintA : !nintB) {  // block-uniform; VALU only inside
+                const int id = (isA ? nz0 - 1 : nz0) + (cz >> 16), ih = (isA ? ny0 - 1 : ny0) + ((cz >> 8) & 255),
+                          iw = (isA ? nx0 - 1 : nx0) + (cz & 255);
+                const bool ok = id >= 0 && id < (isA ? g.Di : g.Db) && ih >= 0 && ih < (isA ? g.Hi : g.Hb) && iw >= 0 &&
+                                iw < (isA ? g.Wi : g.Wb);
+                o = ok ? o : 0xffffffffu;
+            }
+            const u32x4w q4 = __builtin_amdgcn_raw_buffer_load_b128(isA ? rA : rB, (int)o, 0, 0);
+            const float4 f4 = __builtin_bit_cast(float4, q4);
+            if (isA) ra[ua] = f4;
+            else rb[ub] = f4;
+        };
         MVD_WGS(4)
         // window of the first quad: columns 0..3 of quad row 0, and its dy quad
         {
@@ -1725,8 +1767,8 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-        for (int hq = 0; hq < 4; hq++) {
+        // one quad row = four steps; WL: the next tile's loads ride behind the steps' MFMAs, two per step (DB, row 0)
+        auto quad_row = [&](int hq, auto WL) {
 #pragma unroll
             for (int wq = 0; wq < 4; wq++) {
                 constexpr int dummy = 0;
@@ -1784,8 +1826,20 @@ __device__ __forceinline__ void wgrad_wino2_body(const WgradGeom &g, const WgTil
                     V[nxt][gz][2] = r2 - r1;
                     V[nxt][gz][3] = r1 - r3;
                 }
+                if constexpr (decltype(WL)::value) {
+                    issue_load(2 * wq);
+                    issue_load(2 * wq + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if constexpr (DB) {
+            quad_row(0, std::true_type{});
+#pragma unroll 1
+            for (int hq = 1; hq < 4; hq++) quad_row(hq, std::false_type{});
+        } else {
+#pragma unroll 1
+            for (int hq = 0; hq < 4; hq++) quad_row(hq, std::false_type{});
         }
         MVD_WGS(5)
         if (DB) {
@@ -2113,7 +2167,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_smallc(const WgradGeom g, cons
 // NA / NB: uint4 (8 channels) per thread of the A halo / B tile.  Same split-K / prefetch structure as k_wgrad_mfma.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 
 __device__ inline bf16x8w tr_operand(const unsigned char *p0, const unsigned char *p1) {
