@@ -1150,6 +1150,66 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const 
     const bool aok = part * 4 < cvalid, bok = part * 4 < kvalid;
 
     float4 ra[NA], rb[NB];
+    // Two LDS images and the next tile's loads as unconditional buffer loads with tile-independent lane offsets (the
+    // form k_wgrad_wino2w12 took): one barrier per tile; no slot decode, bounds compares or 64-bit address
+    // per load for interior tiles.  db = false (MVD_WGRAD_DB=0): the single image and load_tile() below.
+    const bool db = !(tg.dbg & 16);
+    unsigned relA[NA], relB[NB];  // byte offsets from the tile's first halo voxel (channel block and part folded in)
+    int czA[NA], czB[NB];         // packed halo coordinates, -1 = this lane loads nothing for slot u
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+        const int idx = u * 512 + tid, slot = idx >> 3;
+        const int ez = (slot * tg.magAhw) >> 16, rem = slot - ez * EAhw;
+        const int ey = (rem * tg.magAw) >> 16, ex = rem - ey * tg.EAw;
+        relA[u] = (unsigned)(((ez * g.Hi + ey) * g.Wi + ex) * Cs + cofs + part * 4) * 4u;
+        czA[u] = (aok && idx < na) ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++) {
+        const int idx = u * 512 + tid, slot = idx >> 3;
+        const int ez = (slot * tg.magBhw) >> 16, rem = slot - ez * EBhw;
+        const int ey = (rem * tg.magBw) >> 16, ex = rem - ey * tg.EBw;
+        relB[u] = (unsigned)(((ez * g.Hb + ey) * g.Wb + ex) * K + k0 + part * 4) * 4u;
+        czB[u] = (bok && idx < nb) ? ((ez << 16) | (ey << 8) | ex) : -1;
+    }
+    const int EAd = tg.nslotsA / EAhw, EBd = tg.nslotsB / EBhw;  // halo extents along D
+    auto load_tile_buf = [&](int tile) {  // tile >= ntiles: zero-record descriptors, no traffic
+        const bool more = tile < tg.ntiles;
+        unsigned r_ = (unsigned)(more ? tile : 0);
+        const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+        const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+        const int td_ = (int)(r_ % (unsigned)tg.ntd);
+        const int n = (int)(r_ / (unsigned)tg.ntd);
+        const int od0 = td_ * tg.TD, oh0 = th_ * tg.TH, ow0 = tw_ * tg.TW;
+        const int za = od0 * g.sa[0] + tg.minA[0], ya = oh0 * g.sa[1] + tg.minA[1], xa = ow0 * g.sa[2] + tg.minA[2];
+        const int zb = od0 * g.sb[0] + tg.minB[0], yb = oh0 * g.sb[1] + tg.minB[1], xb = ow0 * g.sb[2] + tg.minB[2];
+        const bool intA = za >= 0 && za + EAd <= g.Di && ya >= 0 && ya + tg.EAh <= g.Hi && xa >= 0 && xa + tg.EAw <= g.Wi;
+        const bool intB = zb >= 0 && zb + EBd <= g.Db && yb >= 0 && yb + tg.EBh <= g.Hb && xb >= 0 && xb + tg.EBw <= g.Wb;
+        const float *baseA = asrc + ((((long)n * g.Di + za) * g.Hi + ya) * g.Wi + xa) * (long)Cs;
+        const float *baseB = b + ((((long)n * g.Db + zb) * g.Hb + yb) * g.Wb + xb) * (long)K;
+        const __amdgpu_buffer_rsrc_t rA =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(baseA), 0, more ? 0x7fffffff : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(baseB), 0, more ? 0x7fffffff : 0, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            unsigned o = czA[u] >= 0 ? relA[u] : 0xffffffffu;
+            if (!intA) {  // block-uniform; VALU only inside
+                const int id = za + (czA[u] >> 16), ih = ya + ((czA[u] >> 8) & 255), iw = xa + (czA[u] & 255);
+                o = (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi) ? o : 0xffffffffu;
+            }
+            ra[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, (int)o, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            unsigned o = czB[u] >= 0 ? relB[u] : 0xffffffffu;
+            if (!intB) {
+                const int id = zb + (czB[u] >> 16), ih = yb + ((czB[u] >> 8) & 255), iw = xb + (czB[u] & 255);
+                o = (id >= 0 && id < g.Db && ih >= 0 && ih < g.Hb && iw >= 0 && iw < g.Wb) ? o : 0xffffffffu;
+            }
+            rb[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rB, (int)o, 0, 0));
+        }
+    };
     auto load_tile = [&](int tile) {
         unsigned r_ = (unsigned)tile;
         const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
@@ -1190,11 +1250,12 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const 
             }
         }
     };
-    auto store_tile = [&]() {  // unconditional: the LDS regions hold NA*512 / NB*512 float4
+    constexpr int IMG = (NA + NB) * 2048;  // floats of one image pair
+    auto store_tile = [&](int par) {  // unconditional: the LDS regions hold NA*512 / NB*512 float4
 #pragma unroll
-        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + (size_t)(u * 512 + tid) * 4) = ra[u];
+        for (int u = 0; u < NA; u++) *reinterpret_cast<float4 *>(As + par * IMG + (size_t)(u * 512 + tid) * 4) = ra[u];
 #pragma unroll
-        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + (size_t)(u * 512 + tid) * 4) = rb[u];
+        for (int u = 0; u < NB; u++) *reinterpret_cast<float4 *>(Bs + par * IMG + (size_t)(u * 512 + tid) * 4) = rb[u];
     };
     // operands of k-step s2 (k = voxel pair).  Byte offsets: slot*128 + lane column; the per-tap part is hoisted.
     // The lane half h is the second voxel of the pair: s2 is even and TW a power of two >= 2, so (s2 + h) only changes
@@ -1239,14 +1300,21 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const 
         }
     };
 
-    int tile = split;
+    int tile = split, par = 0;
     if (tile < tg.ntiles) load_tile(tile);
-    while (tile < tg.ntiles) {
-        __syncthreads();  // every wave is done reading the previous tile
-        store_tile();
+    if (db) {
+        if (tile < tg.ntiles) store_tile(0);
         __syncthreads();
+    }
+    while (tile < tg.ntiles) {
+        if (!db) {
+            __syncthreads();  // every wave is done reading the previous tile
+            store_tile(0);
+            __syncthreads();
+        }
         const int next = tile + tg.nsplit;
-        if (next < tg.ntiles) load_tile(next);  // in flight during this tile's MFMAs
+        if (db) load_tile_buf(next);  // in flight during this tile's MFMAs
+        else if (next < tg.ntiles) load_tile(next);
         // branch-free k loop unrolled by two with ping-pong operand registers: the LDS reads of step s+1 are issued
         // under the MFMAs of step s (left alone, the scheduler sinks every read next to its MFMA and each MFMA then
         // eats a full LDS round trip)
@@ -1264,6 +1332,13 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_mfma(const WgradGeom g, const 
                 interleave();
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (db) {  // the next tile goes into the other image; one barrier per tile
+            if (next < tg.ntiles) store_tile(par ^ 1);
+            __syncthreads();
+            par ^= 1;
+            Ab = reinterpret_cast<const char *>(As + par * IMG);
+            Bb = reinterpret_cast<const char *>(Bs + par * IMG);
         }
         tile = next;
     }
@@ -2390,12 +2465,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
 #endif
     int tile = split;
     if (tile < tg.ntiles) load_tile(tile);
-    if (TRI && tg.dbg > 0) {
-        // experiment (MVD_WG16_DELAY): the second workgroup of a CU starts half a tile period late
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if ((lin >> 8) & 1)
-            for (int d = 0; d < tg.dbg; d++) __builtin_amdgcn_s_sleep(16);
-    }
     while (tile < tg.ntiles) {
         MVD_WGS(0)
         __syncthreads();
@@ -2734,10 +2803,12 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     float *partial = reinterpret_cast<float *>(ws);
     const int tpw = (g.ntaps + 3) / 4;
     dim3 grid(tg.nsplit, ncb * tg.nkb);
+    static const int db_mfma = getenv("MVD_WGRAD_DB") ? atoi(getenv("MVD_WGRAD_DB")) : 1;  // two LDS images (k_wgrad_mfma)
+    if (!bf16_in) tg.dbg = (tg.dbg & ~16) | (db_mfma ? 0 : 16);
 #define WG_LAUNCH(TPW, NA, NB, SH)                                                                                   \
     {                                                                                                              \
         auto kern = k_wgrad_mfma<TPW, NA, NB, SH>;                                                                 \
-        const size_t lds = (size_t)(NA + NB) * 8192;                                                               \
+        const size_t lds = (size_t)(NA + NB) * 8192 * (db_mfma ? 2 : 1);                                           \
         static bool cfgd = false;                                                                                  \
         if (!cfgd) {                                                                                               \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -2766,9 +2837,6 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         // TRI: the x-triples of the plain 27-tap stride-1 gather share their halo-row reads (see k_wgrad16)
         static int tri_env = -1;
         if (tri_env < 0) tri_env = getenv("MVD_WGRAD16_TRI") ? atoi(getenv("MVD_WGRAD16_TRI")) : 1;
-        static int delay_env = -1;
-        if (delay_env < 0) delay_env = getenv("MVD_WG16_DELAY") ? atoi(getenv("MVD_WG16_DELAY")) : 0;
-        tg.dbg = delay_env;
         bool tri = tri_env != 0 && sameB && tpw == 7 && g.ntaps == 27 && tg.TW == 8 && g.sa[2] == 1 &&
                    tg.TD * tg.TH * tg.TW == (cfg == 2 ? 256 : 128);
         for (int t = 0; t < 27 && tri; t++) tri = tg.toffA[t] == tg.toffA[t - t % 3] + t % 3;
