@@ -9,7 +9,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-f = sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True))[-1]
+f = max(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)  # newest
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
 sgd = [i for i, r in enumerate(rows) if "k_sgd" in r[2]]
