@@ -97,6 +97,10 @@ def test_conv3d_two_pointer_concat_equals_cat():
     (96, 0, 32, (6, 7, 8), (1, 2, 2), 1),  # anisotropic stride
     (4, 0, 32, (10, 9, 8), 1, 2),        # the 4-channel input layer (CK=4)
     (8, 0, 32, (7, 6, 5), 1, 1),         # CK=8 layout
+    (32, 0, 32, (18, 36, 44), 1, 2),     # Winograd wgrad tile loop: 540 ragged tiles over 256 workgroups (two LDS images,
+                                         # buffer loads with out-of-range lanes, zero-record descriptors after the last tile)
+    (32, 32, 32, (20, 40, 24), 1, 2),    # the same with two input pointers (128 workgroups per channel block)
+    (32, 0, 64, (40, 44, 68), 2, 2),     # generic wgrad tile loop (stride 2): several ragged tiles per workgroup
 ])
 def test_conv3d_engine_shapes_vs_torch_fp64(C1, C2, K, sp, stride, N):
     from multimodal_mvd_seg_amd import ops
