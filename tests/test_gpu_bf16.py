@@ -203,6 +203,8 @@ def close_f32(a, ref, what, rel=2e-5):
     (32, 0, 64, (16, 12, 20), 2, 1),
     (320, 320, 320, (4, 4, 4), 1, 2),
     (128, 0, 128, (6, 7, 8), (1, 2, 2), 1),
+    (32, 0, 32, (34, 44, 52), 1, 2),     # 256-voxel tiles, 756 ragged tiles over 512 workgroups: the x-triple step loop with
+                                         # the next tile's buffer loads (out-of-range lanes, zero-record descriptors)
 ])
 def test_conv3d_bf16_wgrad(C1, C2, K, sp, stride, N):
     """dw/dbias from bf16 x and bf16 dy are fp32-accumulated sums of exact products: compare with fp64 on the same
