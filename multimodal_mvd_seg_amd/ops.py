@@ -335,6 +335,21 @@ def _out_dim(i, k, s):
 
 
 # ======================================================================================================== conv
+class LaunchTimer:
+    """bench.py: HIP events (on the stream the kernels run on) around the forward launches of ONE conv layer shape while
+    the timed train steps run -- the in-step duration of the roofline kernel.  key = (bf16, N, C1, C2, K, D, H, W, kernel,
+    stride); inactive unless `on`."""
+
+    def __init__(self, key):
+        self.key, self.pairs, self.on = tuple(key), [], False
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs) if self.pairs else None
+
+
+LAUNCH_TIMER = None
+
+
 class Conv3dFn(Function):
     """Conv3d(k in {1,3}, pad=(k-1)/2, stride in {1,2}) over the channel concat of x1 and (optional) x2.
     Replaces nn.Conv3d of ConvDropoutNormReLU and torch.cat((x, skip), 1) (UNetDecoder.py:107)."""
@@ -359,6 +374,11 @@ class Conv3dFn(Function):
         y = empty_cl3d((N, K, *od), x1.device, x1.dtype)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, od[0] * od[1] * od[2], K), x1.device)
         ub = None
+        tm = LAUNCH_TIMER
+        timed = tm is not None and tm.on and tm.key == (bf, N, C1, C2, K, D, H, W, tuple(ks), tuple(stride))
+        if timed:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if bf:
             wf, wb = _packed_bf16(weight, False)
             call("mvd_conv3d_fwd_bf16", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
@@ -384,6 +404,10 @@ class Conv3dFn(Function):
             else:
                 call("mvd_conv3d_fwd_wino", _p(x1), C1, _p(x2), C2, _p(wf), _p(uf), _p(bias), _p(y), N, D, H, W, K, i3(ks),
                      i3(stride), _p(ws), ws.numel(), _stream())
+        if timed:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            tm.pairs.append((ev0, ev1))
         ctx.bf = bf
         ctx.params = (weight, bias)
         ctx.pack = None if bf else (pk, pk.gen)
