@@ -7,6 +7,8 @@
 // line) straight from HBM and its weight fragment (16 floats, packed layout of conv_geom.h) from L2, both one step
 // ahead of the MFMAs; no barrier anywhere.  The gathered-tap engines ran these as T one-tap launches (each re-reading
 // x and writing a strided eighth of y): 3 ms per step for 16 GFLOP; these kernels are bound by the HBM stream.
+#include <algorithm>
+#include <stdlib.h>
 #include "common.h"
 #include "conv_geom.h"
 
@@ -113,6 +115,95 @@ __global__ __launch_bounds__(256, 4) void k_convT_fwd(const TranspGeom g, const 
             for (int j = 0; j < 2; j++)
                 if (j < np) y[(size_t)(ob + poff[j]) * g.K + k] = acc[j][r] + bv;
         }
+    }
+}
+
+// Persistent form for the top level (64 -> 32 channels, 2x2x2 up-sampling): the kernel above gives a wave 32
+// MFMAs per 32-channel chunk -- two chunks at the 64 -> 32 level -- between an HBM round trip for its operands and 32
+// scattered stores, 352 us where the traffic (0.67 GB) and the MFMAs (17 GFLOP) each need ~0.13 ms.  Here a wave keeps its
+// two positions' weights in registers for the whole launch (NCH x 32 registers), walks the 32-voxel blocks with a grid
+// stride and has the next block's x rows in flight while it computes and stores the current one.
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void k_convT_fwd_p(const TranspGeom g, const float *__restrict__ x,
+                                                                       const float *__restrict__ wf,
+                                                                       const float *__restrict__ bias, float *__restrict__ y,
+                                                                       int nblk) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int p0 = wave * 2;  // T == 8: two positions per wave
+    const int kb = blockIdx.y;
+    // packed weights [cc][t][h][k][16]
+    const float *wl = wf + (((size_t)h * g.K + kb * 32 + i) << 4);
+    const size_t wtap = (size_t)2 * g.K * 16;
+    float4 wr[NCH][2][4];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                wr[c][j][e] = *reinterpret_cast<const float4 *>(wl + ((size_t)c * g.T + p0 + j) * wtap + e * 4);
+    const int k = kb * 32 + i;
+    const float bv = settled(bias ? bias[k] : 0.f);
+    const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    int poff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int p = p0 + j;
+        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+        poff[j] = (pd * Hy + ph) * Wy + pw;
+    }
+    float4 a[2][NCH][4];
+    auto load_a = [&](int blk, float4 (&dst)[NCH][4]) {
+        const long vv = (long)blk * 32 + i;
+        const long v = vv < g.NV ? vv : g.NV - 1;  // clamp: rows past the end are computed and dropped
+        const float *xl = x + (size_t)v * g.C + h * 16;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) dst[c][e] = *reinterpret_cast<const float4 *>(xl + c * 32 + e * 4);
+    };
+    int blk = blockIdx.x;
+    if (blk >= nblk) return;
+    load_a(blk, a[0]);
+    for (int it = 0; blk < nblk; blk += gridDim.x, it++) {
+        const int nxt = blk + (int)gridDim.x < nblk ? blk + (int)gridDim.x : blk;  // (the last trip re-reads its own rows)
+        auto trip = [&](float4 (&cur)[NCH][4], float4 (&nx)[NCH][4]) {
+            load_a(nxt, nx);  // unconditional: in flight under this block's MFMAs and stores
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[c][e].x, wr[c][j][e].x, acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[c][e].y, wr[c][j][e].y, acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[c][e].z, wr[c][j][e].z, acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[c][e].w, wr[c][j][e].w, acc[j], 0, 0, 0);
+                }
+            const long vb = (long)blk * 32;
+            const long vv = vb + i;
+            const int ob_own = (int)out_base(g, (unsigned)(vv < g.NV ? vv : g.NV - 1));  // < 2^31 (host-checked)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ob = __shfl(ob_own, row, 64);  // lane `row` (lower half) holds voxel vb + row
+                if (vb + row < g.NV) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) y[(size_t)(ob + poff[j]) * g.K + k] = acc[j][r] + bv;
+                }
+            }
+        };
+        if (it & 1) trip(a[1], a[0]);
+        else trip(a[0], a[1]);
     }
 }
 
@@ -377,6 +468,13 @@ int convT_fwd_direct(const float *x, const float *wf, const float *bias, float *
     if (((uintptr_t)x | (uintptr_t)wf) & 15) return -1;
     const long bx = (g.NV + 31) / 32;
     if (bx > (1L << 30) || K / 32 > 65535) return -1;
+    static const int pers = getenv("MVD_CONVT_PERSIST") ? atoi(getenv("MVD_CONVT_PERSIST")) : 1;
+    if (pers && g.T == 8 && C == 64 && K == 32 && bx >= 4096) {
+        // persistent, weights resident in registers (64 of the wave's 256): two workgroups per CU
+        const unsigned gx = (unsigned)std::min<long>(bx, 512);
+        hipLaunchKernelGGL(k_convT_fwd_p<2>, dim3(gx, 1), dim3(256), 0, s, g, x, wf, bias, y, (int)bx);
+        return check_launch("convT fwd (persistent direct GEMM)");
+    }
     hipLaunchKernelGGL(k_convT_fwd, dim3((unsigned)bx, K / 32), dim3(256), 0, s, g, x, wf, bias, y);
     return check_launch("convT fwd (direct GEMM)");
 }

@@ -225,6 +225,7 @@ def test_convT3d(name):
     (320, 320, (2, 2, 2), (2, 2, 2), 2),    # bottleneck up-sampling, split-reduce
     (128, 64, (5, 6, 7), (2, 2, 2), 1),     # ragged
     (64, 32, (4, 6, 5), (1, 2, 2), 1),      # anisotropic
+    (64, 32, (33, 41, 53), (2, 2, 2), 2),   # the persistent forward kernel of the top level (>= 4096 blocks), ragged tail
 ])
 def test_convT3d_engine_shapes_vs_torch_fp64(C, K, sp, stride, N):
     from multimodal_mvd_seg_amd import ops
