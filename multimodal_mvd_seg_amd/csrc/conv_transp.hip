@@ -295,6 +295,73 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 3) void k_convT_dgrad(const Tran
         }
 }
 
+// Persistent input gradient for the top level (K = 32 reduce channels, 2x2x2): a wave = one 32-channel block of dx, its
+// eight positions' weights resident in registers (128 of its 256), 32-voxel groups walked with a grid stride; the dy rows
+// of position p + 1 (the last position: position 0 of the wave's next group) are in flight under the 16 MFMAs of
+// position p.  Same reasons as k_convT_fwd_p: the one-group-per-wave kernel spends its time in operand round trips.
+__global__ __launch_bounds__(256, 2) void k_convT_dgrad_p(const TranspGeom g, const float *__restrict__ dy,
+                                                         const float *__restrict__ wb, float *__restrict__ dx, int ngrp) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ncb = g.C >> 5;
+    const int cb = wave % ncb;             // host: 4 % ncb == 0
+    const int gsub = wave / ncb, gper = 4 / ncb;  // voxel groups per workgroup
+    const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    // packed weights (reduce K, produce C): [kc][t][h][c][16], kc == 0
+    const float *wl = wb + (((size_t)h * g.C + cb * 32 + i) << 4);
+    const size_t wtap = (size_t)2 * g.C * 16;
+    float4 wr[8][4];
+    int poff[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) wr[p][e] = *reinterpret_cast<const float4 *>(wl + (size_t)p * wtap + e * 4);
+        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+        poff[p] = (pd * Hy + ph) * Wy + pw;
+    }
+    const int c = cb * 32 + i;
+    const int gstride = (int)gridDim.x * gper;
+    int grp = (int)blockIdx.x * gper + gsub;
+    if (grp >= ngrp) return;
+    auto row_ptr = [&](int gq) {  // this lane's dy row of group gq at position 0 (clamped past the end: computed, dropped)
+        const long vv = (long)gq * 32 + i;
+        const long ob = out_base(g, (unsigned)(vv < g.NV ? vv : g.NV - 1));
+        return dy + (size_t)ob * g.K + h * 16;
+    };
+    const float *rp = row_ptr(grp);
+    float4 a[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) a[0][e] = *reinterpret_cast<const float4 *>(rp + (size_t)poff[0] * g.K + e * 4);
+    for (; grp < ngrp; grp += gstride) {
+        const int gn = grp + gstride < ngrp ? grp + gstride : grp;  // (the last trip re-reads its own first row)
+        const float *rn = row_ptr(gn);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const float *pn = p < 7 ? rp + (size_t)poff[p < 7 ? p + 1 : 0] * g.K : rn + (size_t)poff[0] * g.K;
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[(p + 1) & 1][e] = *reinterpret_cast<const float4 *>(pn + e * 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][e].x, wr[p][e].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][e].y, wr[p][e].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][e].z, wr[p][e].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p & 1][e].w, wr[p][e].w, acc, 0, 0, 0);
+            }
+        }
+        const long vb = (long)grp * 32;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (vb + row < g.NV) dx[(size_t)(vb + row) * g.C + c] = acc[r];
+        }
+        rp = rn;
+    }
+}
+
 // ================================================================================================ bf16 twins
 // Same two GEMMs on v_mfma_f32_32x32x16_bf16: a 32-channel chunk is two k-steps; lane (i, h) reads the 8 bf16 reduce
 // channels s*16 + h*8 .. +7 of its voxel (16 bytes) and its weight fragment [..][s][h][k][8] of conv_bf16.hip's layout.
@@ -489,6 +556,13 @@ int convT_dgrad_direct(const float *dy, const float *wb, float *dx, int N, int D
     // one 32-channel block per wave (93 registers: five waves per SIMD hide the operand round trips) while dy is re-read
     // at most 4 times; two blocks per wave for the wide low-resolution stages
     const int ncb = C / 32;
+    static const int pers = getenv("MVD_CONVT_PERSIST") ? atoi(getenv("MVD_CONVT_PERSIST")) : 1;
+    const long ngrp = (g.NV + 31) / 32;
+    if (pers && g.T == 8 && K == 32 && (ncb == 1 || ncb == 2 || ncb == 4) && ngrp >= 4096 && ngrp < (1L << 30)) {
+        const long nb = (ngrp * ncb + 3) / 4;  // workgroups if every wave had one group
+        hipLaunchKernelGGL(k_convT_dgrad_p, dim3((unsigned)std::min<long>(nb, 512)), dim3(256), 0, s, g, dy, wb, dx, (int)ngrp);
+        return check_launch("convT dgrad (persistent direct GEMM)");
+    }
     if (ncb > 4 && ncb % 2 == 0) {
         hipLaunchKernelGGL(k_convT_dgrad<2>, dim3((unsigned)bx, ncb / 2), dim3(256), 0, s, g, dy, wb, dx);
     } else {

@@ -25,5 +25,9 @@ for (C, K, S) in [(64, 32, 64), (128, 64, 32), (256, 128, 16), (320, 256, 8)]:
         return e0.elapsed_time(e1) / a.iters
     with torch.no_grad():
         tf = t(fwd)
+    def fb():
+        x.grad = None
+        ops.ConvTranspose3dFn.apply(x, w.detach(), b.detach(), (2, 2, 2)).backward(gy)
+    tb = t(fb) - tf  # forward + input gradient - forward
     gb = (x.numel() + y.numel()) * x.element_size() / 1e9
-    print(f"convT {C}->{K} @{S}^3 {a.dtype}: fwd {tf:.3f} ms  {gb / tf:.2f} TB/s (x + y)")
+    print(f"convT {C}->{K} @{S}^3 {a.dtype}: fwd {tf:.3f} ms  {gb / tf:.2f} TB/s (x + y); dgrad {tb:.3f} ms  {gb / tb:.2f} TB/s")
