@@ -8,6 +8,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python
 F=$(ls /tmp/prof_$TAG/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -z "$F" ] && { echo "no stats file"; exit 1; }
 cp "$F" $OUT/${TAG}_kernel_stats.csv
+mkdir -p $OUT/${TAG}_trace && cp "${F%kernel_stats.csv}kernel_trace.csv" $OUT/${TAG}_trace/ 2>/dev/null || true
 python3 - "$F" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
