@@ -450,6 +450,89 @@ __global__ __launch_bounds__(256, 4) void k_convT_fwd16(const TranspGeom g, cons
     }
 }
 
+// persistent form of the forward for the top level (C = 64, K = 32, 2x2x2), as k_convT_fwd_p: the one-block kernel gives a
+// wave EIGHT MFMAs between its operand round trip and its stores
+__global__ __launch_bounds__(256, 3) void k_convT_fwd16_p(const TranspGeom g, const unsigned short *__restrict__ x,
+                                                          const unsigned short *__restrict__ wf,
+                                                          const float *__restrict__ bias, unsigned short *__restrict__ y,
+                                                          int nblk) {
+    constexpr int NCH = 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int p0 = wave * 2;
+    // packed weights [cc][t][s][h][k][8]
+    const unsigned short *wl = wf + (((size_t)h * g.K + i) << 3);
+    const size_t ws_ = (size_t)2 * g.K * 8, wtap = 2 * ws_;
+    bf16x8t wr[NCH][2][2];  // [chunk][position][k-step]
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) wr[c][j][s2] = ld_bf8(wl + ((size_t)c * g.T + p0 + j) * wtap + s2 * ws_);
+    const int Hy = g.H * g.s[1], Wy = g.W * g.s[2];
+    float4 bq[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++)
+        bq[rg] = settled(bias ? *reinterpret_cast<const float4 *>(bias + 8 * rg + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f));
+    long poff[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int p = p0 + j;
+        const int pw = p % g.s[2], ph = (p / g.s[2]) % g.s[1], pd = p / (g.s[2] * g.s[1]);
+        poff[j] = ((long)pd * Hy + ph) * Wy + pw;
+    }
+    bf16x8t a[2][NCH][2];
+    auto load_a = [&](int blk, bf16x8t (&dst)[NCH][2]) {
+        const long vv = (long)blk * 32 + i;
+        const unsigned short *xl = x + (size_t)(vv < g.NV ? vv : g.NV - 1) * g.C + h * 8;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) dst[c][s2] = ld_bf8(xl + c * 32 + s2 * 16);
+    };
+    int blk = blockIdx.x;
+    if (blk >= nblk) return;
+    load_a(blk, a[0]);
+    for (int it = 0; blk < nblk; blk += gridDim.x, it++) {
+        const int nxt = blk + (int)gridDim.x < nblk ? blk + (int)gridDim.x : blk;
+        auto trip = [&](bf16x8t (&cur)[NCH][2], bf16x8t (&nx)[NCH][2]) {
+            load_a(nxt, nx);
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[c][j][s2], cur[c][s2], acc[j], 0, 0, 0);  // D^T
+            const long vv = (long)blk * 32 + i;
+            if (vv < g.NV) {
+                const long ob = out_base(g, (unsigned)vv);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    unsigned short *yo = y + (size_t)(ob + poff[j]) * g.K + 4 * h;
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) {
+                        const float4 b4 = bq[rg];
+                        uint2 q;
+                        q.x = (unsigned)f2bf(acc[j][rg * 4 + 0] + b4.x) | ((unsigned)f2bf(acc[j][rg * 4 + 1] + b4.y) << 16);
+                        q.y = (unsigned)f2bf(acc[j][rg * 4 + 2] + b4.z) | ((unsigned)f2bf(acc[j][rg * 4 + 3] + b4.w) << 16);
+                        *reinterpret_cast<uint2 *>(yo + 8 * rg) = q;
+                    }
+                }
+            }
+        };
+        if (it & 1) trip(a[1], a[0]);
+        else trip(a[0], a[1]);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256, 4) void k_convT_dgrad16(const TranspGeom g, const unsigned short *__restrict__ dy,
                                                           const unsigned short *__restrict__ wb,
@@ -578,6 +661,11 @@ int convT_fwd_direct16(const unsigned short *x, const unsigned short *wf, const 
     if (((uintptr_t)x | (uintptr_t)wf) & 15) return -1;
     const long bx = (g.NV + 31) / 32;
     if (bx > (1L << 30) || K / 32 > 65535) return -1;
+    static const int pers = getenv("MVD_CONVT_PERSIST") ? atoi(getenv("MVD_CONVT_PERSIST")) : 1;
+    if (pers && g.T == 8 && C == 64 && K == 32 && bx >= 4096) {
+        hipLaunchKernelGGL(k_convT_fwd16_p, dim3((unsigned)std::min<long>(bx, 1024)), dim3(256), 0, s, g, x, wf, bias, y, (int)bx);
+        return check_launch("convT fwd (bf16 persistent direct GEMM)");
+    }
     hipLaunchKernelGGL(k_convT_fwd16, dim3((unsigned)bx, K / 32), dim3(256), 0, s, g, x, wf, bias, y);
     return check_launch("convT fwd (bf16 direct GEMM)");
 }

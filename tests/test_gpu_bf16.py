@@ -160,7 +160,8 @@ def test_bf16_packs_follow_the_fused_optimizer_in_one_launch():
     assert not torch.equal(conv.weight._mvd_pack16[1], old_wf)
 
 
-@pytest.mark.parametrize("C,K,sp,N", [(64, 32, (4, 5, 6), 2), (320, 256, (2, 2, 2), 2)])
+@pytest.mark.parametrize("C,K,sp,N", [(64, 32, (4, 5, 6), 2), (320, 256, (2, 2, 2), 2),
+                                      (64, 32, (33, 41, 53), 2)])  # the persistent top-level forward, ragged tail
 def test_convT3d_bf16_fwd_dgrad(C, K, sp, N):
     from multimodal_mvd_seg_amd._lib import call, i3, query
     g = torch.Generator().manual_seed(C + K)
