@@ -566,26 +566,27 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
         if (fastst) {
             const unsigned off0 = (unsigned)(((iy0 + r3) * g.Wi + iw) * Cs + cofs + part * 4) << 2;  // bytes, used when ok
             const unsigned drow = (unsigned)(3 * g.Wi * Cs) << 2;
+            // all 15 loads of a thread in ONE round trip, as unconditional buffer loads: a plane outside the volume gets a
+            // zero-record descriptor, a lane outside it an out-of-range offset -- both read zeros.  (Predicated loads kept
+            // the staging at three serialised batches of five: a branch around a load makes the compiler wait for the
+            // loads before it.)
+            float4 v[15];
 #pragma unroll
-            for (int base = 0; base < 15; base += 5) {
-                float4 v[5];
+            for (int pl = 0; pl < 5; pl++) {
+                const int id = iz0 + pl;  // plane: wave-uniform
+                const bool inpl = id >= 0 && id < g.Di;
+                const float *plane = src + ((size_t)n * g.Di + (inpl ? id : 0)) * g.Hi * g.Wi * Cs;
+                const __amdgpu_buffer_rsrc_t rp =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(plane), 0, inpl ? 0x7fffffff : 0, 0x00020000);
 #pragma unroll
-                for (int q = 0; q < 5; q++) {
-                    const int pq = base + q, id = iz0 + pq / 3;  // plane: wave-uniform
-                    const float *plane = src + ((size_t)n * g.Di + id) * g.Hi * g.Wi * Cs;
-                    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (okr[pq % 3] && id >= 0 && id < g.Di) {
-                        unsigned o = off0 + (unsigned)(pq % 3) * drow;
-                        asm("" : "+v"(o));  // scalar plane base + 32-bit lane offset
-                        v[q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(plane) + o);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 5; q++) {
-                    const int pq = base + q;
-                    if (st_act) lds_st[((pq / 3) * 9 + 3 * (pq % 3)) * 17 * (XS / 4)] = v[q];
+                for (int r = 0; r < 3; r++) {
+                    const unsigned o = okr[r] ? off0 + (unsigned)r * drow : 0xffffffffu;
+                    v[pl * 3 + r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)o, 0, 0));
                 }
             }
+#pragma unroll
+            for (int pq = 0; pq < 15; pq++)
+                if (st_act) lds_st[((pq / 3) * 9 + 3 * (pq % 3)) * 17 * (XS / 4)] = v[pq];
         } else {
             int tid_ = tid;
             asm volatile("" : "+v"(tid_));
