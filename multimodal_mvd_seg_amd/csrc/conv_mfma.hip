@@ -725,16 +725,29 @@ __global__ __launch_bounds__(512, 2) void k_dgrad32s(const FwdGeom g, const Dg2T
 
     for (int kk = 0; kk < nch; kk++) {
         __syncthreads();
-        for (int idx = tid; idx < 135 * 8; idx += 512) {
-            const int slot = idx >> 3, part = idx & 7;
-            const int ez = slot / 45, rem = slot - ez * 45;
-            const int ey = rem / 9, ex = rem - ey * 9;
-            const int oz = oz0 + ez, oy = oy0 + ey, ox = ox0 + ex;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oz < g.Di && oy < g.Hi && ox < g.Wi)
-                v = *reinterpret_cast<const float4 *>(dy + ((((size_t)n * g.Di + oz) * g.Hi + oy) * g.Wi + ox) * K + kk * 32 +
-                                                      part * 4);
-            *reinterpret_cast<float4 *>(Xs + (size_t)slot * XS + part * 4) = v;
+        {
+            // the thread's (up to three) 16-byte pieces of the 3 x 5 x 9 dy tile in ONE round trip: unconditional buffer
+            // loads, out-of-range offset (-> zeros) for voxels outside the volume and for pieces past the tile.  One
+            // predicated load per loop trip, stored before the next was issued, cost a round trip per piece.
+            const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(dy + (size_t)n * g.Di * g.Hi * g.Wi * K + kk * 32), 0, 0x7fffffff, 0x00020000);
+            float4 v[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int idx = tid + u * 512;
+                const int slot = idx >> 3, part = idx & 7;
+                const int ez = slot / 45, rem = slot - ez * 45;
+                const int ey = rem / 9, ex = rem - ey * 9;
+                const int oz = oz0 + ez, oy = oy0 + ey, ox = ox0 + ex;
+                const bool ok = idx < 135 * 8 && oz < g.Di && oy < g.Hi && ox < g.Wi;
+                const unsigned o = ok ? (unsigned)(((oz * g.Hi + oy) * g.Wi + ox) * K + part * 4) * 4u : 0xffffffffu;
+                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)o, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int idx = tid + u * 512;
+                if (idx < 135 * 8) *reinterpret_cast<float4 *>(Xs + (size_t)(idx >> 3) * XS + (idx & 7) * 4) = v[u];
+            }
         }
         __syncthreads();
         const float *wc = wlane + (size_t)kk * 27 * wtap;
@@ -802,6 +815,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad32s(const FwdGeom g, const Dg2T
 int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const float *dy, const float *wb, float *dx,
              hipStream_t s) {
     if (C % 32 || K % 32 || (((uintptr_t)dy | (uintptr_t)wb) & 15)) return -1;
+    if ((long)Do * Ho * Wo * K * 4 >= (1L << 31)) return -1;  // 32-bit byte offsets inside one sample of dy (buffer loads)
     FwdGeom g;
     memset(&g, 0, sizeof(g));
     g.N = N;
