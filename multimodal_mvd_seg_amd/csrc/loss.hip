@@ -131,25 +131,25 @@ __global__ __launch_bounds__(256) void k_seghead_fwd_voxp(const float *__restric
 #pragma unroll
     for (int k = 0; k < KMAX; k++) acc[k] = 0.f;
     const size_t xo = ((size_t)n * V + (live ? v : 0)) * C;
+    // C % 32 == 0 (host): every load below is unconditional -- a dead lane reads voxel 0 and drops its result.  (With a
+    // predicate on each load the compiler waited for load j before it issued load j + 1: eight round trips per chunk.)
     for (int c0 = p * 32; c0 < C; c0 += 32 * P) {
         float4 q[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            q[j] = (live && c0 + 4 * j < C) ? ld4<XB>(x, xo + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 8; j++) q[j] = ld4<XB>(x, xo + c0 + 4 * j);
 #pragma unroll
         for (int k = 0; k < KMAX; k++)
-            if (k < K) {
+            if (k < K) {  // uniform
                 const float *wk = w + (size_t)k * C + c0;
                 float a = acc[k];
 #pragma unroll
-                for (int j = 0; j < 8; j++)
-                    if (c0 + 4 * j < C) {
-                        const float4 w4 = *reinterpret_cast<const float4 *>(wk + 4 * j);
-                        a += q[j].x * w4.x;
-                        a += q[j].y * w4.y;
-                        a += q[j].z * w4.z;
-                        a += q[j].w * w4.w;
-                    }
+                for (int j = 0; j < 8; j++) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(wk + 4 * j);
+                    a += q[j].x * w4.x;
+                    a += q[j].y * w4.y;
+                    a += q[j].z * w4.z;
+                    a += q[j].w * w4.w;
+                }
                 acc[k] = a;
             }
     }
