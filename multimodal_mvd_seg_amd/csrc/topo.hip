@@ -79,15 +79,14 @@ __global__ void k_erode_bwd(const uint16_t *__restrict__ code, const float *__re
         for (int a = 0; a < 3; a++) {
 #pragma unroll
             for (int o = -1; o <= 1; o += 2) {
-                int q = pos[a] + o;  // output voxel at offset o along axis a; this voxel sits at -o in its window
-                if (q < 0 || q >= len[a]) continue;
-                long j = i + (long)o * st[a];
-                uint16_t c = code[j];
-                if ((int)((c >> (2 * a)) & 3) == (1 - o)) {
-                    float s[3];
-                    erode_shares(c, s);
-                    g += s[a] * dy[j];
-                }
+                const int q = pos[a] + o;  // output voxel at offset o along axis a; this voxel sits at -o in its window
+                const bool ok = q >= 0 && q < len[a];
+                const long j = ok ? i + (long)o * st[a] : i;  // (unconditional loads, selected afterwards: see k_dilate_bwd)
+                const uint16_t c = code[j];
+                const float gy = dy[j];
+                float s[3];
+                erode_shares(c, s);
+                g = (ok && (int)((c >> (2 * a)) & 3) == (1 - o)) ? g + s[a] * gy : g;
             }
         }
         dx[i] = g;
@@ -131,20 +130,23 @@ __global__ void k_dilate_bwd(const uint8_t *__restrict__ code, const float *__re
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i % DHW;
         int d = (int)(r / HW), h = (int)((r % HW) / W), w = (int)(r % W);
+        // All 27 (code, dy) pairs are loaded unconditionally (a neighbour outside the volume reads this voxel and is
+        // ignored) and accumulated by selects in the same order: with `continue` / `if` around the loads the compiler
+        // waited for each one before issuing the next -- 54 dependent round trips per voxel, 107 us for a 17-MB volume.
         float g = 0.f;
-        for (int a = -1; a <= 1; a++) {
-            if (d + a < 0 || d + a >= D) continue;
-            for (int b = -1; b <= 1; b++) {
-                if (h + b < 0 || h + b >= H) continue;
+#pragma unroll
+        for (int a = -1; a <= 1; a++)
+#pragma unroll
+            for (int b = -1; b <= 1; b++)
 #pragma unroll
                 for (int c = -1; c <= 1; c++) {
-                    if (w + c < 0 || w + c >= W) continue;
-                    long j = i + a * HW + b * W + c;  // output voxel; this voxel is at (-a,-b,-c) in its window
-                    int want = (1 - a) * 9 + (1 - b) * 3 + (1 - c);
-                    if ((int)code[j] == want) g += dy[j];
+                    const bool ok = d + a >= 0 && d + a < D && h + b >= 0 && h + b < H && w + c >= 0 && w + c < W;
+                    const long j = ok ? i + a * HW + b * W + c : i;  // output voxel; this voxel is at (-a,-b,-c) in its window
+                    const int want = (1 - a) * 9 + (1 - b) * 3 + (1 - c);
+                    const int cj = (int)code[j];
+                    const float gy = dy[j];
+                    g = (ok && cj == want) ? g + gy : g;
                 }
-            }
-        }
         dx[i] = g;
     }
 }
@@ -250,12 +252,29 @@ __global__ __launch_bounds__(256) void k_skel_iter_fwd(const float *__restrict__
     const long vbase = nc * D * HW;
     const float *src = img + vbase;
     // stage A: the image with a halo of 3
-    for (int idx = tid; idx < SK_AZ * SK_AY * SK_AX; idx += 256) {
-        const int lx = idx % SK_AX, ly = (idx / SK_AX) % SK_AY, lz = idx / (SK_AX * SK_AY);
-        const int gz = z0 + lz - 3, gy = y0 + ly - 3, gx = x0 + lx - 3;
-        float v = INFINITY;
-        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) v = src[(long)gz * HW + (long)gy * W + gx];
-        A[idx] = v;
+    // (unconditional loads from clamped coordinates, four in flight per thread, padded by a select afterwards: a predicate
+    // around the load made every trip of this loop a memory round trip of its own)
+    {
+        constexpr int NA_ = SK_AZ * SK_AY * SK_AX;
+        for (int base = 0; base < NA_; base += 4 * 256) {
+            float v[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 256 + tid;
+                const int ii = idx < NA_ ? idx : 0;
+                const int lx = ii % SK_AX, ly = (ii / SK_AX) % SK_AY, lz = ii / (SK_AX * SK_AY);
+                const int gz = z0 + lz - 3, gy = y0 + ly - 3, gx = x0 + lx - 3;
+                in[u] = gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int cz = min(max(gz, 0), D - 1), cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+                v[u] = src[(long)cz * HW + (long)cy * W + cx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 256 + tid;
+                if (idx < NA_) A[idx] = in[u] ? v[u] : INFINITY;
+            }
+        }
     }
     __syncthreads();
     // stage B: e1 = erode(img) on the tile + halo 2
