@@ -90,10 +90,17 @@ __global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict
 #pragma unroll
     for (int k = 0; k < KMAX; k++) acc[k] = 0.f;
     const size_t xo = ((size_t)n * V + v) * C;
+    const bool full = (C & 31) == 0;  // every 32-channel chunk whole: the loads need no predicate (a predicate around a load
+                                      // makes the compiler wait for the loads before it: eight round trips per chunk)
     for (int c0 = 0; c0 < C; c0 += 32) {
         float4 q[8];
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) q[j] = (c0 + 4 * j < C) ? ld4<XB>(x, xo + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 8; j++) q[j] = ld4<XB>(x, xo + c0 + 4 * j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = (c0 + 4 * j < C) ? ld4<XB>(x, xo + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int k = 0; k < KMAX; k++)
             if (k < K) {
@@ -185,10 +192,16 @@ __global__ __launch_bounds__(256) void k_seghead_dx4(const float *__restrict__ d
         float4 a[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // all class gradients of the quad in flight at once: classes >= K read class K - 1 again (their weights are zero and
+        // the arithmetic below skips them); behind `k < K` each load waited for the one before it
+        float4 dq[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+            dq[k] = *reinterpret_cast<const float4 *>(dl + ((size_t)n * K + (k < K ? k : K - 1)) * V + 4 * q);
 #pragma unroll
         for (int k = 0; k < KMAX; k++)
             if (k < K) {
-                const float4 d = *reinterpret_cast<const float4 *>(dl + ((size_t)n * K + k) * V + 4 * q);
+                const float4 d = dq[k];
                 const float dv[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -340,10 +353,14 @@ __global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restr
             float4 q[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) q[u] = ld4<XB>(x, (size_t)(i + u) * C + g * 4);
+            float4 dq[KMAX];  // (all classes in flight at once, see k_seghead_dx4)
+#pragma unroll
+            for (int k = 0; k < KMAX; k++)
+                dq[k] = *reinterpret_cast<const float4 *>(dl + ((size_t)n * K + (k < K ? k : K - 1)) * V + v);
 #pragma unroll
             for (int k = 0; k < KMAX; k++)
                 if (k < K) {
-                    const float4 d = *reinterpret_cast<const float4 *>(dl + ((size_t)n * K + k) * V + v);
+                    const float4 d = dq[k];
                     acc[k][0] += d.x * q[0].x + d.y * q[1].x + d.z * q[2].x + d.w * q[3].x;
                     acc[k][1] += d.x * q[0].y + d.y * q[1].y + d.z * q[2].y + d.w * q[3].y;
                     acc[k][2] += d.x * q[0].z + d.y * q[1].z + d.z * q[2].z + d.w * q[3].z;
