@@ -410,11 +410,10 @@ __global__ void k_dcce_fwd(const float *__restrict__ logits, const float *__rest
         float z[KMAX];
         float m = -INFINITY;
 #pragma unroll
+        for (int k = 0; k < KMAX; k++) z[k] = ln[(size_t)(k < K ? k : K - 1) * V + v];  // all classes in flight (no predicate)
+#pragma unroll
         for (int k = 0; k < KMAX; k++)
-            if (k < K) {
-                z[k] = ln[(size_t)k * V + v];
-                m = fmaxf(m, z[k]);
-            }
+            if (k < K) m = fmaxf(m, z[k]);
         const int y = label_of(tn[v], K);
         float s = 0.f, zy = 0.f;
 #pragma unroll
@@ -528,11 +527,10 @@ __global__ void k_dcce_bwd(const float *__restrict__ logits, const float *__rest
         float z[KMAX];
         float m = -INFINITY;
 #pragma unroll
+        for (int k = 0; k < KMAX; k++) z[k] = ln[(size_t)(k < K ? k : K - 1) * V + v];  // all classes in flight (no predicate)
+#pragma unroll
         for (int k = 0; k < KMAX; k++)
-            if (k < K) {
-                z[k] = ln[(size_t)k * V + v];
-                m = fmaxf(m, z[k]);
-            }
+            if (k < K) m = fmaxf(m, z[k]);
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; k++)
@@ -600,11 +598,10 @@ __global__ void k_softmax_select(const float *__restrict__ logits, const float *
         float z[KMAX];
         float m = -INFINITY;
 #pragma unroll
+        for (int k = 0; k < KMAX; k++) z[k] = ln[(size_t)(k < K ? k : K - 1) * V + v];  // all classes in flight (no predicate)
+#pragma unroll
         for (int k = 0; k < KMAX; k++)
-            if (k < K) {
-                z[k] = ln[(size_t)k * V + v];
-                m = fmaxf(m, z[k]);
-            }
+            if (k < K) m = fmaxf(m, z[k]);
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; k++)
