@@ -19,8 +19,17 @@ __global__ void k_reduce_partials(const double *__restrict__ partials, float *__
                                   int offset) {
     // one wave per output value, lanes stride over blocks, fixed shuffle tree -> deterministic
     int j = blockIdx.x;
-    double s = 0;
-    for (int b = threadIdx.x; b < nblk; b += 64) s += partials[(size_t)b * stride + offset + j];
+    // four loads in flight per lane (a lane's trips were one dependent round trip each: up to 128 of them for the
+    // seg-head weight gradient), combined in a fixed order
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int b = threadIdx.x;
+    for (; b + 192 < nblk; b += 256) {
+        const double v0 = partials[(size_t)b * stride + offset + j], v1 = partials[(size_t)(b + 64) * stride + offset + j];
+        const double v2 = partials[(size_t)(b + 128) * stride + offset + j], v3 = partials[(size_t)(b + 192) * stride + offset + j];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; b < nblk; b += 64) s0 += partials[(size_t)b * stride + offset + j];
+    double s = (s0 + s1) + (s2 + s3);
     s = wave_sum(s);
     if (threadIdx.x == 0) out[j] = (float)s;
 }

@@ -88,14 +88,20 @@ __global__ void k_in_finalize(const double *__restrict__ partial, float *__restr
                               int C, int nblk, long V, float eps) {
     // one wave per (n, c): lanes stride over the block partials, fixed shuffle tree (deterministic)
     const int n = blockIdx.y, c = blockIdx.x;
-    double a = 0, q = 0;
-    for (int b = threadIdx.x; b < nblk; b += 64) {
+    double a = 0, q = 0, a1 = 0, q1 = 0;
+    int b = threadIdx.x;
+    for (; b + 64 < nblk; b += 128) {  // two block partials (four loads) in flight per lane, fixed order
+        const size_t o = (((size_t)n * nblk + b) * C + c) * 2, o1 = (((size_t)n * nblk + b + 64) * C + c) * 2;
+        const double va = partial[o], vq = partial[o + 1], wa = partial[o1], wq = partial[o1 + 1];
+        a += va; q += vq; a1 += wa; q1 += wq;
+    }
+    for (; b < nblk; b += 64) {
         size_t o = (((size_t)n * nblk + b) * C + c) * 2;
         a += partial[o];
         q += partial[o + 1];
     }
-    a = wave_sum(a);
-    q = wave_sum(q);
+    a = wave_sum(a + a1);
+    q = wave_sum(q + q1);
     if (threadIdx.x != 0) return;
     double m = a / (double)V;
     double var = q / (double)V - m * m;
@@ -359,14 +365,20 @@ __global__ void k_in_bwd_finalize(const double *__restrict__ partial, float *__r
     const int c = blockIdx.x;
     double tg = 0, tb = 0;
     for (int n = 0; n < N; n++) {
-        double a = 0, q = 0;
-        for (int b = threadIdx.x; b < nblk; b += 64) {
+        double a = 0, q = 0, a1 = 0, q1 = 0;
+        int b = threadIdx.x;
+        for (; b + 64 < nblk; b += 128) {  // (as k_in_finalize)
+            const size_t o = (((size_t)n * nblk + b) * C + c) * 2, o1 = (((size_t)n * nblk + b + 64) * C + c) * 2;
+            const double va = partial[o], vq = partial[o + 1], wa = partial[o1], wq = partial[o1 + 1];
+            a += va; q += vq; a1 += wa; q1 += wq;
+        }
+        for (; b < nblk; b += 64) {
             size_t o = (((size_t)n * nblk + b) * C + c) * 2;
             a += partial[o];
             q += partial[o + 1];
         }
-        a = wave_sum(a);
-        q = wave_sum(q);
+        a = wave_sum(a + a1);
+        q = wave_sum(q + q1);
         if (threadIdx.x == 0) {
             sums[((size_t)n * C + c) * 2 + 0] = (float)a;
             sums[((size_t)n * C + c) * 2 + 1] = (float)q;
