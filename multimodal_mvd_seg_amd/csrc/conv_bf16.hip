@@ -377,7 +377,16 @@ __global__ void k_split_reduce16(const FwdGeom g, const float *__restrict__ part
     const size_t per = (size_t)g.N * g.Do * g.Ho * g.Wo * K;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
         float s = bias ? bias[idx % K] : 0.f;
-        for (int j = 0; j < S; j++) s += part[(size_t)j * per + idx];
+        int j = 0;
+        for (; j + 3 < S; j += 4) {  // four partials in flight, added in split order (same sum as one at a time)
+            const float p0 = part[(size_t)j * per + idx], p1 = part[(size_t)(j + 1) * per + idx];
+            const float p2 = part[(size_t)(j + 2) * per + idx], p3 = part[(size_t)(j + 3) * per + idx];
+            s += p0;
+            s += p1;
+            s += p2;
+            s += p3;
+        }
+        for (; j < S; j++) s += part[(size_t)j * per + idx];
         const int k = (int)(idx % K);
         size_t r = idx / K;
         const int ow = (int)(r % g.Wo);
