@@ -2071,7 +2071,21 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce_wino2(const float *__rest
     if (j < nout) {
         const long gz = j / CK, ck = j - gz * CK;
         const float *src = partial + ((size_t)(gz * 4 + a) * 4) * CK + ck;
-        for (int sp = q; sp < nsplit; sp += 4) {
+        int sp = q;
+        for (; sp + 4 < nsplit; sp += 8) {  // two splits = eight loads in flight per thread, added in split order
+            float v0[4], v1[4];
+#pragma unroll
+            for (int bq = 0; bq < 4; bq++) {
+                v0[bq] = src[(size_t)sp * per + (size_t)bq * CK];
+                v1[bq] = src[(size_t)(sp + 4) * per + (size_t)bq * CK];
+            }
+#pragma unroll
+            for (int bq = 0; bq < 4; bq++) {
+                m[bq] += (double)v0[bq];
+                m[bq] += (double)v1[bq];
+            }
+        }
+        for (; sp < nsplit; sp += 4) {
 #pragma unroll
             for (int bq = 0; bq < 4; bq++) m[bq] += (double)src[(size_t)sp * per + (size_t)bq * CK];
         }
