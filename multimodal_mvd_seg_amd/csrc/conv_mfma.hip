@@ -1976,8 +1976,18 @@ __global__ __launch_bounds__(1024) void k_dbias_reduce(const float *__restrict__
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + e;
     double s = 0;
-    if (k < K)
-        for (int r = q; r < nrows; r += 16) s += (double)pbias[(size_t)r * K + k];
+    if (k < K) {
+        int r = q;
+        for (; r + 48 < nrows; r += 64) {  // four rows in flight, added in row order
+            const float v0 = pbias[(size_t)r * K + k], v1 = pbias[(size_t)(r + 16) * K + k];
+            const float v2 = pbias[(size_t)(r + 32) * K + k], v3 = pbias[(size_t)(r + 48) * K + k];
+            s += (double)v0;
+            s += (double)v1;
+            s += (double)v2;
+            s += (double)v3;
+        }
+        for (; r < nrows; r += 16) s += (double)pbias[(size_t)r * K + k];
+    }
     red[q][e] = s;
     __syncthreads();
     if (q != 0 || k >= K) return;
