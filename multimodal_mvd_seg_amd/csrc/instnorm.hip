@@ -124,12 +124,25 @@ __global__ void k_in_tiles_reduce(const float *__restrict__ tile, double *__rest
     for (int c0 = 0; c0 < C; c0 += CW) {
         const int c = c0 + tc;
         double a = 0, q = 0;
-        if (r < R && c < C)
-            for (long tt = t0 + r; tt < t1; tt += R) {
-                const float2 v = *reinterpret_cast<const float2 *>(tile + (((size_t)n * ntiles + tt) * C + c) * 2);
+        if (r < R && c < C) {
+            const float *tp = tile + ((size_t)n * ntiles * C + c) * 2;
+            long tt = t0 + r;
+            for (; tt + 3L * R < t1; tt += 4L * R) {  // four tiles in flight, added in tile order
+                const float2 v0 = *reinterpret_cast<const float2 *>(tp + (size_t)tt * C * 2);
+                const float2 v1 = *reinterpret_cast<const float2 *>(tp + (size_t)(tt + R) * C * 2);
+                const float2 v2 = *reinterpret_cast<const float2 *>(tp + (size_t)(tt + 2L * R) * C * 2);
+                const float2 v3 = *reinterpret_cast<const float2 *>(tp + (size_t)(tt + 3L * R) * C * 2);
+                a += (double)v0.x; q += (double)v0.y;
+                a += (double)v1.x; q += (double)v1.y;
+                a += (double)v2.x; q += (double)v2.y;
+                a += (double)v3.x; q += (double)v3.y;
+            }
+            for (; tt < t1; tt += R) {
+                const float2 v = *reinterpret_cast<const float2 *>(tp + (size_t)tt * C * 2);
                 a += (double)v.x;
                 q += (double)v.y;
             }
+        }
         __syncthreads();
         if (r < R) {
             sm[((size_t)r * CW + tc) * 2 + 0] = a;
