@@ -50,7 +50,24 @@ __global__ void k_in_stats(const float *__restrict__ x, double *__restrict__ par
     for (int i = 0; i < VEC; i++) s[i] = ss[i] = 0.0;
     if (r < R) {
         const float *xp = x + ((size_t)n * V) * C + (size_t)g * VEC;
-        for (long v = v0 + r; v < v1; v += R) {
+        long v = v0 + r;
+        if (VEC == 4) {
+            for (; v + 3L * R < v1; v += 4L * R) {  // four rows in flight per thread, accumulated in row order
+                float4 q4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) q4[u] = ld4<XB>(x, ((size_t)n * V + v + (long)u * R) * C + (size_t)g * 4);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float f[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        s[i] += (double)f[i];
+                        ss[i] += (double)f[i] * (double)f[i];
+                    }
+                }
+            }
+        }
+        for (; v < v1; v += R) {
             if (VEC == 4) {
                 float4 q = ld4<XB>(x, ((size_t)n * V + v) * C + (size_t)g * 4);
                 float f[4] = {q.x, q.y, q.z, q.w};
