@@ -349,7 +349,26 @@ __global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restr
             be[i] = beta[c];
         }
         const size_t base = ((size_t)n * V) * C + (size_t)g * VEC;
-        for (long v = v0 + r; v < v1; v += R) {
+        long v = v0 + r;
+        if (VEC == 4) {
+            for (; v + R < v1; v += 2L * R) {  // two rows (four loads) in flight per thread, accumulated in row order
+                const float4 q0 = ld4<XB>(x, base + (size_t)v * C), e0 = ld4<YB>(dy, base + (size_t)v * C);
+                const float4 q1 = ld4<XB>(x, base + (size_t)(v + R) * C), e1 = ld4<YB>(dy, base + (size_t)(v + R) * C);
+                const float fx[2][4] = {{q0.x, q0.y, q0.z, q0.w}, {q1.x, q1.y, q1.z, q1.w}};
+                const float dd[2][4] = {{e0.x, e0.y, e0.z, e0.w}, {e1.x, e1.y, e1.z, e1.w}};
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float xh = (fx[u][i] - mu[i]) * rs[i];
+                        const float z = xh * ga[i] + be[i];
+                        const float dz = z > 0.f ? dd[u][i] : dd[u][i] * slope;
+                        s[i] += (double)dz;
+                        ss[i] += (double)dz * (double)xh;
+                    }
+            }
+        }
+        for (; v < v1; v += R) {
             float f[VEC], d[VEC];
             if (VEC == 4) {
                 float4 q = ld4<XB>(x, base + (size_t)v * C);
