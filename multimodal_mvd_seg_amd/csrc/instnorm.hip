@@ -260,6 +260,10 @@ __global__ void k_in_apply_rows(const float *__restrict__ x, const float *__rest
     }
 }
 
+#ifndef MVD_IN_NRB
+#define MVD_IN_NRB 4
+#endif
+constexpr int NRB = MVD_IN_NRB;  // rows in flight per thread in the backward apply pass
 template <bool XB, bool YB>
 __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__restrict__ dy,
                                     const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -287,15 +291,15 @@ __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__
     }
     const size_t base = ((size_t)n * V) * C + (size_t)g * 4;
     long v = v0 + r;
-    for (; v + 1L * R < v1; v += 2L * R) {  // two rows (four loads) in flight
-        float4 q[2], e[2];
+    for (; v + (NRB - 1L) * R < v1; v += (long)NRB * R) {  // NRB rows (2 NRB loads) in flight
+        float4 q[NRB], e[NRB];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NRB; u++) {
             q[u] = ld4<XB>(x, base + (size_t)(v + (long)u * R) * C);
             e[u] = ld4<YB>(dy, base + (size_t)(v + (long)u * R) * C);
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NRB; u++) {
             float f[4] = {q[u].x, q[u].y, q[u].z, q[u].w}, d[4] = {e[u].x, e[u].y, e[u].z, e[u].w};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
