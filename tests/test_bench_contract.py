@@ -61,3 +61,17 @@ def test_bench_line_has_the_contract_keys_and_in_step_roofline():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.0 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["launches_timed_in_step"] == 3  # one forward launch of the roofline layer per timed step
+
+
+@pytest.mark.gpu
+def test_bench_line_bf16_reports_the_hbm_roofline_of_the_block():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--precision", "bf16", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["dtype"] == "bf16" and "bf16" in d["metric"] and d["steps"] == 3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches_timed_in_step"] == 6  # the two 32 -> 32 forward launches at the patch, per timed step
+    assert abs(r["achieved"] - r["algorithmic_GB_per_launch"] / (r["ms_per_launch"] * 1e-3)) < 0.01 * r["achieved"]
