@@ -95,6 +95,32 @@ def test_ds_scales_and_weights_follow_the_reference():
     assert np.allclose(t._get_deep_supervision_scales(), SO.ds_scales(c["strides"]))
     assert len(t._get_deep_supervision_scales()) == 5
     assert np.allclose(losses.ds_weights(5), LO.ds_weights(5))
+    # the reference method itself, executed on a stub trainer (tests/golden/ds_scales.json)
+    d = json.load(open(os.path.join(GOLDEN, "ds_scales.json")))
+    for c in d["cases"]:
+        t.configuration_manager = trainer.PlansManager(trainer.make_plans(
+            (64, 64, 64), c["pool_op_kernel_sizes"])).get_configuration("3d_fullres")
+        assert [list(map(float, i)) for i in t._get_deep_supervision_scales()] == c["scales"]
+    t.enable_deep_supervision = False
+    assert t._get_deep_supervision_scales() is d["disabled"]
+
+
+def test_configure_optimizers_hyperparameters_equal_the_reference_method():
+    """nnUNetTrainer.configure_optimizers (:473-477) executed on a stub trainer -> ds_scales.json["optimizer"]: the fused
+    optimizer the product's configure_optimizers builds carries the same hyper-parameters and schedule (host side only;
+    the arithmetic of its step is a -m gpu test)."""
+    o = json.load(open(os.path.join(GOLDEN, "ds_scales.json")))["optimizer"]
+    t = trainer.nnUNetTrainerMI355.__new__(trainer.nnUNetTrainerMI355)
+    t.network, t.initial_lr, t.weight_decay, t.num_epochs = nn.Linear(3, 2), 1e-2, 3e-5, o["num_epochs"]
+    opt, sch = t.configure_optimizers()   # construction only: flat buffers on the parameters' (cpu) device, no kernel
+    g0 = opt.param_groups[0]
+    for k, v in o["hyper"].items():
+        if k != "dampening":              # SGD's dampening is 0 in the reference call; the fused kernel has none
+            assert g0[k] == v, k
+    assert o["hyper"]["dampening"] == 0 and opt.max_grad_norm == 12   # clip_grad_norm_(..., 12), nnUNetTrainer.py:918/923
+    for e, lr in enumerate(o["lrs"]):
+        sch.step(e)
+        assert opt.param_groups[0]["lr"] == lr
 
 
 def test_plans_inheritance():

@@ -335,8 +335,109 @@ def loss_fixtures():
          pred=p, target=t, loss=l, gpred=p.grad)
 
 
+class _RefStepHarness:
+    """The reference's own step code on a stub trainer (nothing of its text is stored; see ref_function):
+    * `nnUNetTrainer.train_step` (nnUNetTrainer.py:888-925) -- executed unchanged with `autocast` / `dummy_context`
+      injected (the device is cpu, so the reference takes its dummy_context branch) and its debug prints muted;
+    * `nnUNetTrainer.configure_optimizers` (:473-477) -- executed unchanged; `PolyLRScheduler` is a shim whose `step`
+      is the reference's own `PolyLRScheduler.step` (polylr.py:13-20; the ctor passes a `verbose` positional that
+      torch 2.10's LRScheduler no longer takes, an ordinary TypeError);
+    * `nnUNetTrainer._get_deep_supervision_scales` (:296-302);
+    * `UNetDecoder_return_last_fea.forward` (UNetDecoder.py:1001-1027) -- the fork's plain decoder forward (no
+      attention insert, `attn_skip = skips[-1]`), executed with `self` = the oracle decoder module, which holds the
+      `stages / transpconvs / seg_layers / deep_supervision` attributes the body reads.
+    The encoder blocks, the loss classes and the MVD composite stay the oracle's restatement (un-vendored
+    `dynamic_network_architectures`, three loss files missing from the fork: SURVEY 8c)."""
+    TR = "training/nnUNetTrainer/nnUNetTrainer.py"
+
+    def __init__(self):
+        import contextlib
+        import types
+        quiet = lambda *a, **k: None
+        self.types = types
+        self.train_step, self.src_step = ref_function(self.TR, "train_step", "nnUNetTrainer", autocast=torch.autocast,
+                                                      dummy_context=contextlib.nullcontext, print=quiet)
+        poly = ref_module("training/lr_scheduler/polylr.py", "ref_poly_step")
+
+        class PolyShim:
+            def __init__(sh, optimizer, initial_lr, max_steps, exponent=0.9, current_step=None):
+                sh.optimizer, sh.initial_lr, sh.max_steps, sh.exponent, sh.ctr = optimizer, initial_lr, max_steps, exponent, 0
+            step = poly.PolyLRScheduler.step
+
+        self.configure_optimizers, self.src_opt = ref_function(self.TR, "configure_optimizers", "nnUNetTrainer",
+                                                               PolyLRScheduler=PolyShim)
+        self.ds_scales, self.src_ds = ref_function(self.TR, "_get_deep_supervision_scales", "nnUNetTrainer")
+        self.dec_forward, self.src_dec = ref_function("training/my_network/UNetDecoder.py", "forward",
+                                                      "UNetDecoder_return_last_fea", print=quiet)
+
+    def network(self, net):
+        """encoder (oracle) -> the reference's decoder forward.  Returns a callable with the `parameters()` the trainer
+        methods use and a `.last` slot holding the outputs of the latest call."""
+        h = self
+
+        class Net:
+            last = None
+
+            def __call__(s, x):
+                skips = net.encoder(x)
+                r = h.dec_forward(net.decoder, skips, skips[-1])
+                s.last = r
+                return r[0] if net.decoder.deep_supervision else r
+
+            def parameters(s):
+                return net.parameters()
+        return Net()
+
+    def trainer(self, net, loss_fn, num_epochs=200):
+        me = self.types.SimpleNamespace(network=self.network(net), loss=loss_fn, device=torch.device("cpu"),
+                                        grad_scaler=None, initial_lr=1e-2, weight_decay=3e-5, num_epochs=num_epochs)
+        me.optimizer, me.lr_scheduler = self.configure_optimizers(me)
+        return me
+
+    def scales(self, strides, enabled=True):
+        me = self.types.SimpleNamespace(enable_deep_supervision=enabled,
+                                        configuration_manager=self.types.SimpleNamespace(pool_op_kernel_sizes=strides))
+        return self.ds_scales(me)
+
+
+def _assert_same_state(net_a, net_b, what):
+    for (n, a), (_, b) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), (what, n)
+        if a.grad is not None or b.grad is not None:
+            assert torch.equal(a.grad, b.grad), (what, "grad", n)
+
+
+def ds_scales_fixture(H):
+    cases = []
+    for strides in ([[1, 1, 1]] + [[2, 2, 2]] * 5, [[1, 1, 1]] + [[2, 2, 2]] * 4, [[1, 1, 1], [2, 2, 2], [2, 2, 2]],
+                    [[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 2], [1, 2, 2]], [[1, 1, 1]]):
+        sc = H.scales(strides)
+        assert [list(map(float, i)) for i in sc] == [list(map(float, i)) for i in SO.ds_scales(strides)]
+        cases.append({"pool_op_kernel_sizes": strides, "scales": [[float(v) for v in i] for i in sc]})
+    assert H.scales([[1, 1, 1], [2, 2, 2]], enabled=False) is None
+    # configure_optimizers (:473-477) on a stub trainer: the SGD hyper-parameters and the schedule it attaches
+    me = H.types.SimpleNamespace(network=torch.nn.Linear(2, 2), initial_lr=1e-2, weight_decay=3e-5, num_epochs=50)
+    opt, sch = H.configure_optimizers(me)
+    g0 = opt.param_groups[0]
+    hp = {k: g0[k] for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov")}
+    lrs = []
+    for e in range(50):
+        sch.step(e)
+        lrs.append(opt.param_groups[0]['lr'])
+    json.dump({"source": "reference " + H.src_ds + " and " + H.src_opt + " (methods executed on a stub trainer)",
+               "cases": cases, "disabled": None,
+               "optimizer": {"class": type(opt).__name__, "hyper": hp, "num_epochs": 50, "lrs": lrs}},
+              open(os.path.join(OUT, "ds_scales.json"), "w"))
+    print("wrote ds_scales.json")
+
+
 def unet_step_fixture():
-    """Tiny end-to-end: 3 stages [8,16,32], C_in=2, K=3, 16^3, B=2 (App. E `unet_tiny_step`)."""
+    """Tiny end-to-end: 3 stages [8,16,32], C_in=2, K=3, 16^3, B=2 (App. E `unet_tiny_step`).  Round 3: the three steps
+    are run by the REFERENCE's train_step / configure_optimizers / decoder forward (_RefStepHarness); the oracle
+    restatement runs beside it on a copy of the network and must agree bit for bit at every step."""
+    import copy
+    H = _RefStepHarness()
+    ds_scales_fixture(H)
     strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
     net = UO.build_plainconv_unet(2, 3, 3, strides, features_per_stage=[8, 16, 32], seed=0)
     # non-trivial norm affine + biases so that every parameter's gradient is exercised
@@ -350,20 +451,33 @@ def unet_step_fixture():
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
     batch = SO.synthetic_batch(2, 2, (16, 16, 16), strides, num_classes=3, seed=1234)
     loss_fn = LO.build_loss(len(batch['target']))
-    opt = SO.make_optimizer(net.parameters())
-    out = {"source": "oracle restatement (unet_oracle + loss_oracle + step_oracle)", "strides": strides,
-           "features": [8, 16, 32], "num_classes": 3, "data": batch['data']}
+    twin = copy.deepcopy(net)                       # the oracle restatement, same start
+    opt_twin = SO.make_optimizer(twin.parameters())
+    me = H.trainer(net, loss_fn)
+    g0 = me.optimizer.param_groups[0]
+    assert isinstance(me.optimizer, torch.optim.SGD) and (g0['lr'], g0['momentum'], g0['weight_decay'], g0['nesterov']) == \
+        (1e-2, 0.99, 3e-5, True)
+    out = {"source": f"reference {H.src_step}, {H.src_opt} (methods executed on a stub trainer; cpu branch), network = "
+                     f"oracle encoder blocks + reference {H.src_dec}; loss = oracle restatement (App. B)",
+           "strides": strides, "features": [8, 16, 32], "num_classes": 3, "data": batch['data']}
     for i, t in enumerate(batch['target']):
         out[f"target{i}"] = t
     for k, v in sd0.items():
         out["sd0/" + k] = v
     for step in range(3):
-        l, logits, gn = SO.train_step(net, loss_fn, opt, batch)
+        r = H.train_step(me, batch)
+        l, (logits, feat) = r['loss'], me.network.last
+        lo, logits_o, gn = SO.train_step(twin, loss_fn, opt_twin, batch)
+        assert l.dtype == np.float32 and np.array_equal(l, lo), (step, l, lo)
+        assert all(torch.equal(a, b) for a, b in zip(logits, logits_o))
+        _assert_same_state(net, twin, f"step {step}")
         out[f"loss{step}"] = l
-        out[f"gradnorm{step}"] = gn
+        out[f"gradnorm{step}"] = gn   # norm before clipping (the reference drops clip_grad_norm_'s return value; the
+        #                               twin's post-clip gradients equal the reference's, asserted above)
         if step == 0:
             for i, lg in enumerate(logits):
                 out[f"logits{i}"] = lg.detach()
+            out["feat"] = feat.detach()
             for n, p in net.named_parameters():
                 out["grad0/" + n] = p.grad.clone()
         for n, p in net.named_parameters():
@@ -373,13 +487,37 @@ def unet_step_fixture():
     out["val_tp"], out["val_fp"], out["val_fn"] = tp, fp, fn
     save("unet_tiny_step.npz", **out)
 
+    # the decoder forward alone: DS on (list + last feature) and DS off (bare tensor), reference vs restatement
+    with torch.no_grad():
+        skips = net.encoder(batch['data'])
+        r_on = H.dec_forward(net.decoder, skips, skips[-1])
+        o_on = net.decoder(skips, True)
+        assert all(torch.equal(a, b) for a, b in zip(r_on[0], o_on[0])) and torch.equal(r_on[1], o_on[1])
+        net.decoder.deep_supervision = False
+        r_off = H.dec_forward(net.decoder, skips, skips[-1])
+        o_off = net.decoder(skips)
+        net.decoder.deep_supervision = True
+        assert torch.is_tensor(r_off) and torch.equal(r_off, o_off) and torch.equal(r_off, r_on[0][0])
+    dec = {"source": "reference " + H.src_dec + " (executed with self = the oracle decoder module)",
+           "strides": strides, "features": [8, 16, 32], "num_classes": 3, "feat": r_on[1], "logits_ds_off": r_off}
+    for i, sk in enumerate(skips):
+        dec[f"skip{i}"] = sk
+    for i, lg in enumerate(r_on[0]):
+        dec[f"logits{i}"] = lg
+    for k, v in net.decoder.state_dict().items():
+        if not k.startswith("encoder."):
+            dec["sd/" + k] = v
+    save("decoder_forward.npz", **dec)
+
     # anisotropic / no-DS variant: strides (1,2,2) then (2,2,2); checks per-axis stride handling
     strides = [[1, 1, 1], [1, 2, 2], [2, 2, 2]]
     net = UO.build_plainconv_unet(1, 2, 3, strides, features_per_stage=[4, 8, 16], seed=1)
     g = gen(61)
     data = torch.rand(1, 1, 8, 16, 12, generator=g)
-    outs = net(data)
-    o = {"source": "oracle", "strides": strides, "features": [4, 8, 16], "num_classes": 2, "data": data}
+    outs = H.network(net)(data)
+    assert all(torch.equal(a, b) for a, b in zip(outs, net(data)))
+    o = {"source": "oracle encoder blocks + reference " + H.src_dec, "strides": strides, "features": [4, 8, 16],
+         "num_classes": 2, "data": data}
     for k, v in net.state_dict().items():
         o["sd0/" + k] = v
     for i, lg in enumerate(outs):
@@ -388,20 +526,43 @@ def unet_step_fixture():
 
 
 def mvd_step_fixture():
+    """Dual-branch step.  The composite loss is the build's restatement (MVDTrainer.py:879-925 is not executable: undefined
+    names); each branch's decoder runs through the REFERENCE's UNetDecoder_return_last_fea.forward, the
+    optimizer comes from the reference's configure_optimizers, and a twin on the oracle's own decoder must agree exactly."""
+    import copy
+    H = _RefStepHarness()
     strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
     n1 = UO.build_plainconv_unet(2, 4, 3, strides, features_per_stage=[8, 16, 32], seed=2)
     n2 = UO.build_plainconv_unet(2, 4, 3, strides, features_per_stage=[8, 16, 32], seed=3)
     net = UO.DualBranchNet(n1, n2)
+    twin = copy.deepcopy(net)
     batch = SO.synthetic_batch(2, 2, (16, 16, 16), strides, num_classes=4, seed=77)
     loss_fn = LO.build_loss(len(batch['target']))
-    opt = SO.make_optimizer(net.parameters())
-    out = {"source": "oracle restatement of MVDTrainer.py:879-925 (see oracle/step_oracle.py)", "strides": strides,
+
+    class RefDecoders:
+        """(logits_1, logits_2, feat_1, feat_2) with both decoders run by the reference's forward."""
+        def __call__(s, x):
+            sk1, sk2 = n1.encoder(x), n2.encoder(x)
+            r1, r2 = H.dec_forward(n1.decoder, sk1, sk1[-1]), H.dec_forward(n2.decoder, sk2, sk2[-1])
+            return r1[0], r2[0], r1[1], r2[1]
+
+        def parameters(s):
+            return net.parameters()
+
+    me = H.types.SimpleNamespace(network=net, initial_lr=1e-2, weight_decay=3e-5, num_epochs=200)
+    opt, _sch = H.configure_optimizers(me)
+    opt_twin = SO.make_optimizer(twin.parameters())
+    out = {"source": "oracle restatement of MVDTrainer.py:879-925 (see oracle/step_oracle.py); decoders run by reference "
+                     + H.src_dec + ", optimizer from reference " + H.src_opt, "strides": strides,
            "features": [8, 16, 32], "num_classes": 4, "data": batch['data'], "skel_iter": 3}
     for i, t in enumerate(batch['target']):
         out[f"target{i}"] = t
     for k, v in net.state_dict().items():
         out["sd0/" + k] = v.clone()
-    l, outs, gn = SO.mvd_train_step(net, loss_fn, opt, batch, use_topo=True, skel_iter=3, feat_kl=True)
+    l, outs, gn = SO.mvd_train_step(RefDecoders(), loss_fn, opt, batch, use_topo=True, skel_iter=3, feat_kl=True)
+    lt, _o, gnt = SO.mvd_train_step(twin, loss_fn, opt_twin, batch, use_topo=True, skel_iter=3, feat_kl=True)
+    assert np.array_equal(l, lt) and gn == gnt
+    _assert_same_state(net, twin, "mvd step")
     out["loss0"], out["gradnorm0"] = l, gn
     for n, p in net.named_parameters():
         out["grad0/" + n] = p.grad.clone()
