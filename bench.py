@@ -60,37 +60,26 @@ def time_kernel(fn, iters, torch):
 
 
 def in_step_roofline(roof, timer):
-    """`achieved` / `frac` from the kernel's average launch duration INSIDE the timed train steps (HIP events around its
-    launches, ops.LaunchTimer); the duration of the same launch repeated back to back after the steps stays beside it as
-    `ms_per_launch_isolated` (it reads 10-15 % longer for the fp32 kernel -- the chip holds a lower clock under an
-    unbroken fp32-MFMA load than under the step's mix -- and ~8 % longer for the bf16 kernel, whose input the step's
-    previous kernel has just written)."""
+    """Adds the kernel's average launch duration INSIDE train steps (HIP events around its launches on the launch stream,
+    ops.LaunchTimer, taken over a few EAGER steps run right after the timed region -- the timed region itself is replayed
+    as one hipGraph launch, inside which no event can be read) as `ms_per_launch_in_step` / `frac_in_step`.
+    `ms_per_launch` / `achieved` / `frac` stay on the isolated, back-to-back launches (round 3, ADVICE r2: like-for-like
+    with round 1 and with the rocprofv3 `--roofline-only` statistics under profiles/)."""
     ms = timer.mean_ms()
     if ms is None:
         return roof
-    iso = roof["ms_per_launch"]
-    k = iso / ms
-    roof["ms_per_launch_isolated"] = iso
-    roof["frac_isolated"] = roof["frac"]
-    roof["ms_per_launch"] = round(ms, 4)
+    k = roof["ms_per_launch"] / ms
+    roof["ms_per_launch_in_step"] = round(ms, 4)
     roof["launches_timed_in_step"] = len(timer.pairs)
-    roof["achieved"] = round(roof["achieved"] * k, 2)
-    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    if "effective_tflops" in roof:  # fp32 view
-        roof["effective_tflops"] = round(roof["effective_tflops"] * k, 2)
-        roof["effective_over_peak"] = round(roof["effective_tflops"] / roof["peak"], 4)
-        roof["hbm_view"]["achieved_GBps"] = round(roof["hbm_view"]["achieved_GBps"] * k, 1)
-        roof["hbm_view"]["frac_of_hbm_peak"] = round(roof["hbm_view"]["achieved_GBps"] / HBM_PEAK_GBS, 4)
-    if "mfma_view" in roof:  # bf16 view
-        roof["mfma_view"]["tflops"] = round(roof["mfma_view"]["tflops"] * k, 1)
-        roof["mfma_view"]["frac"] = round(roof["mfma_view"]["tflops"] / roof["mfma_view"]["peak"], 4)
+    roof["achieved_in_step"] = round(roof["achieved"] * k, 2)
+    roof["frac_in_step"] = round(roof["achieved_in_step"] / roof["peak"], 4)
     return roof
 
 
 def measured_traffic(key="traffic_bytes_per_launch"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in their own runs, gfx950 half-count correction applied): the newest profiles/rNN_pmc_traffic.json
-    that holds `key`."""
+    """(HBM bytes per launch of the dominant kernel, file it came from): the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 half-count correction applied) -- the newest
+    profiles/rNN_pmc_traffic.json that holds `key`.  NOT measured in this run (PMC needs the profiler)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
@@ -98,45 +87,66 @@ def measured_traffic(key="traffic_bytes_per_launch"):
         except (OSError, ValueError):
             continue
         if v is not None:
-            return v
-    return None
+            return v, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def bf16_block_roofline(torch, dev, patch):
-    """bf16 mixed precision (BASELINE configs[3], [4]): the fused conv block of the north_star's HBM target, conv3d
-    32 -> 32 at the full patch, batch 2, bf16 activations, through the entry point ops.Conv3dFn calls.
-    ALGORITHMIC bytes = (C_in*N_in + C_out*N_out) * 2 B: read the producer's output once, write the raw
-    conv output once.  `bound` = hbm (block arithmetic intensity 432 flop/B vs a ridge of ~312); the MFMA view is given
-    beside it."""
-    from multimodal_mvd_seg_amd import ops
+    """bf16 mixed precision (BASELINE configs[3], [4]): the fused conv block of the north_star's HBM target -- Conv3d
+    32 -> 32 (3x3x3) + InstanceNorm3d + LeakyReLU at the full patch, batch 2, bf16 activations -- timed as the network
+    runs it: network.ConvDropoutNormReLU.forward on a resident bf16 NDHWC activation (the conv launch plus EVERY
+    normalisation launch the block needs: statistics / finalize / apply, whatever the current build fuses).
+    ALGORITHMIC bytes = (C_in*N_in + C_out*N_out) * 2 B: read the producer's output once, write the raw conv
+    output once (that byte model ASSUMES the normalisation is fused away; un-fused passes show up as a lower fraction).
+    `achieved` / `frac` = those bytes / the BLOCK's time (round 3).  The conv launch alone (what round
+    2 printed as `frac`) is under `conv_only`; the MFMA view is given beside it."""
+    from multimodal_mvd_seg_amd import network, ops
     from multimodal_mvd_seg_amd._lib import call, i3, query
+    from torch import nn
     import ctypes
     N, C, K = PER_GPU_BATCH, 32, 32
     D, H, W = patch
     x = ops.empty_cl3d((N, C, D, H, W), dev, torch.bfloat16).normal_()
-    w = torch.randn(K, C, 3, 3, 3, device=dev) * 0.05
-    bias = torch.zeros(K, device=dev)
-    wf, _ = ops.pack_weight_bf16(w, False)
+    blk = network.ConvDropoutNormReLU(nn.Conv3d, C, K, 3, 1, True, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, None,
+                                      None, nn.LeakyReLU, {'inplace': True}).to(dev)
+    blk.precision = "bf16"
+    with torch.no_grad():
+        blk.conv.weight.normal_(0, 0.05)
+        blk.norm.weight.uniform_(0.5, 1.5)
+        blk.norm.bias.normal_(0, 0.1)
+    wf, _ = ops.pack_weight_bf16(blk.conv.weight, False)
     y = ops.empty_cl3d((N, K, D, H, W), dev, torch.bfloat16)
     ws = torch.empty(max(1, query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K)), dtype=torch.uint8, device=dev)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def conv():
-        call("mvd_conv3d_fwd_bf16", P(x), C, None, 0, P(wf), P(bias), P(y), N, D, H, W, K, i3((3, 3, 3)), i3((1, 1, 1)),
-             P(ws), ws.numel(), s)
+        call("mvd_conv3d_fwd_bf16", P(x), C, None, 0, P(wf), P(blk.conv.bias), P(y), N, D, H, W, K, i3((3, 3, 3)),
+             i3((1, 1, 1)), P(ws), ws.numel(), s)
+
+    def block():
+        with torch.no_grad():
+            blk(x)
     ms = time_kernel(conv, 10, torch)
+    bms = time_kernel(block, 10, torch)
     V = float(N * D * H * W)
     alg_bytes = (C + K) * V * 2.0
     flops = 2.0 * 27 * C * K * V
-    gbs = alg_bytes / (ms * 1e-3) / 1e9
-    roof = {"kernel": f"conv3d_fwd 32->32 @{'x'.join(map(str, patch))} bf16 (fwd-type implicit GEMM on "
-                      "v_mfma_f32_32x32x16_bf16, z-marching 8x32 columns, weights resident in accumulator registers: k_fwd16z)",
+    gbs = alg_bytes / (bms * 1e-3) / 1e9
+    cgbs = alg_bytes / (ms * 1e-3) / 1e9
+    traffic, tsrc = measured_traffic("traffic_bytes_per_launch_bf16")
+    roof = {"kernel": f"fused block Conv3d 32->32 3x3x3 + InstanceNorm3d + LeakyReLU @{'x'.join(map(str, patch))} bf16, "
+                      "batch 2 (conv: z-marching 8x32 columns on v_mfma_f32_32x32x16_bf16, weights resident in accumulator "
+                      "registers, k_fwd16z; + every InstanceNorm launch of the block)",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_GB_per_launch": round(alg_bytes / 1e9, 4),
-            "traffic": measured_traffic("traffic_bytes_per_launch_bf16"), "ms_per_launch": round(ms, 4),
+            "block_ms": round(bms, 4), "ms_per_launch": round(bms, 4),
+            "traffic": traffic, "traffic_source": f"{tsrc} (conv launch only, committed PMC pass, not measured in this run)",
+            "conv_only": {"ms_per_launch": round(ms, 4), "achieved": round(cgbs, 1), "frac": round(cgbs / HBM_PEAK_GBS, 4),
+                          "note": "the conv launch alone against the block's byte model (round 2's `frac`)"},
+            "instnorm_ms": round(bms - ms, 4),
             "mfma_view": {"tflops": round(flops / (ms * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
-                          "frac": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)}}
+                          "frac": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "of": "conv launch"}}
     g, b = torch.ones(K, device=dev), torch.zeros(K, device=dev)
 
     def norm():
@@ -146,7 +156,7 @@ def bf16_block_roofline(torch, dev, patch):
     ngb = nbytes / (nms * 1e-3) / 1e9
     roof["instnorm_lrelu_fwd"] = {"bound": "hbm", "achieved": round(ngb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(ngb / HBM_PEAK_GBS, 4), "ms_per_launch": round(nms, 4),
-                                  "algorithmic_bytes": "3*C*N*2 (bf16 in, bf16 out)"}
+                                  "algorithmic_bytes": "3*C*N*2 (bf16 in, bf16 out): the stand-alone two-pass form"}
     return roof
 
 
@@ -181,7 +191,8 @@ def dominant_kernel_roofline(torch, dev):
     def conv():
         call("mvd_conv3d_fwd_wino", P(x1), C1, P(x2), C2, P(wf), P(uf) if wino else None, P(bias), P(y), N, D, H, W, K,
              i3((3, 3, 3)), i3((1, 1, 1)), None, 0, s)
-    ms = time_kernel(conv, 3, torch)
+    time_kernel(conv, 3, torch)          # clocks / caches settle
+    ms = time_kernel(conv, 10, torch)
     flops = 2.0 * 27 * (C1 + C2) * K * N * D * H * W
     conv_tf = flops / (ms * 1e-3) / 1e12
     mode = query("mvd_wino_mode") if wino else 0
@@ -198,7 +209,9 @@ def dominant_kernel_roofline(torch, dev):
             "executed_flop_ratio": round(exec_ratio, 4), "effective_tflops": round(conv_tf, 2),
             "effective_over_peak": round(conv_tf / FP32_MFMA_PEAK_TFLOPS, 4),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 1),
-            "traffic": measured_traffic(), "ms_per_launch": round(ms, 3),
+            "traffic": measured_traffic()[0],
+            "traffic_source": f"{measured_traffic()[1]} (committed PMC pass, not measured in this run)",
+            "ms_per_launch": round(ms, 3),
             "hbm_view": {"algorithmic_GB": round(alg_bytes / 1e9, 3),
                          "achieved_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
                          "frac_of_hbm_peak": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
@@ -238,36 +251,57 @@ def usable_cores():
 
 def cpu_baseline(torch):
     """The oracle's torch-CPU train step (same ops, same order as the reference's `-device cpu` path,
-    run_training.py:391-395: all usable host threads, no autocast) on a BOUNDED sample of the workload (target: 10-30 s
-    of CPU work).  A batch-1 step on a 64^3 sub-patch (1/8 of the voxels; every layer is convolutional, so cost scales
-    with voxels) is timed first; if it predicts <= 40 s for the real 4x128^3 patch, ONE batch-1 step at the full patch is
-    timed and reported, otherwise the sub-patch figure scaled by 1/8."""
+    run_training.py:391-395: all usable host threads, no autocast) on a BOUNDED sample of the workload (>= 3
+    timed steps at configs[1], and configs[0] = the reference's own CPU case in full).
+    configs[1]: one batch-1 step on a 64^3 sub-patch first (warms oneDNN up and predicts the cost: every layer is
+    convolutional, so time scales with voxels); if that predicts <= 12 s per full step, THREE batch-1 steps at the full
+    4x128^3 patch are timed (value = 1 / median), otherwise three more sub-patch steps, scaled by 1/8.
+    configs[0] (1 modality, 64^3, batch 2, five stages): one warm-up + three timed steps, reported under `cfg1`."""
     from oracle import loss_oracle as LO, step_oracle as SO, unet_oracle as UO
+    import statistics
     cores = usable_cores()
     torch.set_num_threads(cores)
 
-    def one_step(sub):
-        net = UO.build_plainconv_unet(IN_CH, NUM_CLASSES, 6, STRIDES, seed=0)
-        batch = SO.synthetic_batch(1, IN_CH, sub, STRIDES, num_classes=NUM_CLASSES, seed=1234)
+    def stepper(in_ch, n_stages, strides, sub, batch_size):
+        net = UO.build_plainconv_unet(in_ch, NUM_CLASSES, n_stages, strides, seed=0)
+        batch = SO.synthetic_batch(batch_size, in_ch, sub, strides, num_classes=NUM_CLASSES, seed=1234)
         loss_fn = LO.build_loss(len(batch["target"]))
         opt = SO.make_optimizer(net.parameters())
-        t0 = time.perf_counter()
-        SO.train_step(net, loss_fn, opt, batch)
-        return time.perf_counter() - t0
+
+        def one():
+            t0 = time.perf_counter()
+            SO.train_step(net, loss_fn, opt, batch)
+            return time.perf_counter() - t0
+        return one
 
     sub = (64, 64, 64)
-    dt_sub = one_step(sub)
+    dt_sub = stepper(IN_CH, 6, STRIDES, sub, 1)()
     frac = (sub[0] * sub[1] * sub[2]) / float(PATCH[0] * PATCH[1] * PATCH[2])
-    if dt_sub / frac <= 40.0:
-        dt = one_step(PATCH)
-        return {"value": round(1.0 / dt, 5), "unit": "samples/s", "cores": cores, "kind": "port",
-                "sample": f"1 train step (fwd+loss+bwd+clip+SGD), batch 1, the full 4x128^3 patch, torch "
-                          f"{torch.__version__} CPU fp32, {cores} threads: {dt:.1f} s wall (after a {dt_sub:.1f} s batch-1 "
-                          f"step on a 64^3 sub-patch that also warmed oneDNN up)"}
-    return {"value": round(frac / dt_sub, 5), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step (fwd+loss+bwd+clip+SGD), batch 1, 4x64^3 sub-patch of the 4x128^3 workload, torch "
-                      f"{torch.__version__} CPU fp32, {cores} threads: {dt_sub:.1f} s wall (first step, includes oneDNN "
-                      f"primitive creation); value = (64^3/128^3) / wall"}
+    if dt_sub / frac <= 12.0:
+        one = stepper(IN_CH, 6, STRIDES, PATCH, 1)
+        ts = [one() for _ in range(3)]
+        dt = statistics.median(ts)
+        out = {"value": round(1.0 / dt, 5), "unit": "samples/s", "cores": cores, "kind": "port",
+               "sample": f"3 train steps (fwd+loss+bwd+clip+SGD), batch 1, the full 4x128^3 patch, torch "
+                         f"{torch.__version__} CPU fp32, {cores} threads: {', '.join(f'{t:.1f}' for t in ts)} s wall, value = "
+                         f"1 / median (after a {dt_sub:.1f} s batch-1 step on a 64^3 sub-patch that warmed oneDNN up)"}
+    else:
+        one = stepper(IN_CH, 6, STRIDES, sub, 1)
+        ts = [one() for _ in range(3)]
+        dt = statistics.median(ts)
+        out = {"value": round(frac / dt, 5), "unit": "samples/s", "cores": cores, "kind": "port",
+               "sample": f"3 train steps (fwd+loss+bwd+clip+SGD), batch 1, 4x64^3 sub-patch of the 4x128^3 workload, torch "
+                         f"{torch.__version__} CPU fp32, {cores} threads: {', '.join(f'{t:.1f}' for t in ts)} s wall; value = "
+                         f"(64^3/128^3) / median"}
+    # BASELINE configs[0]: the reference's own CPU-runnable case, in full
+    c1 = UO.CONFIGS["cfg1"]
+    one = stepper(c1["input_channels"], c1["n_stages"], c1["strides"], c1["patch"], 2)
+    one()
+    ts = [one() for _ in range(3)]
+    out["cfg1"] = {"value": round(2.0 / statistics.median(ts), 4), "unit": "samples/s", "cores": cores,
+                   "sample": f"BASELINE configs[0]: 1 modality, 64^3, batch 2, 5 stages (16.55 M parameters): 3 timed steps "
+                             f"after one warm-up: {', '.join(f'{t:.2f}' for t in ts)} s wall, value = 2 / median"}
+    return out
 
 
 def main():
@@ -280,6 +314,9 @@ def main():
                          "shows the timed layer alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 steps a default (configs[1], fp32) run appends")
+    ap.add_argument("--no-graph", action="store_true", help="A/B aid: eager steps (one launch per kernel) instead of the "
+                                                            "hipGraph replay")
     ap.add_argument("--patch", type=int, nargs=3, default=list(PATCH), help="debug only; the metric is quoted at 128^3")
     ap.add_argument("--backend", default="nccl", help="debug only: 'gloo' lets several ranks share one GPU")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
@@ -322,49 +359,71 @@ def main():
             r = roofline()
         print(json.dumps({"roofline": r}), flush=True)
         return
-    plans = trainer.make_plans(patch, STRIDES, batch_size=PER_GPU_BATCH * world)
-    if args.config in ("cfg2", "cfg5"):
-        tr = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, dataset_json(), device=dev)
-    else:
-        tr = trainer.ContrastiveTrainerMI355(plans, "3d_fullres", 0, dataset_json(), device=dev)
-        tr.use_topo = args.config == "cfg4"
-    torch.manual_seed(0)
-    tr.precision = args.precision
-    tr.initialize()
-    if args.config in ("cfg3", "cfg4"):
-        tr.dummy_batch = tr.make_dummy_batch()
-    assert tr.batch_size == PER_GPU_BATCH
-    tr.on_train_epoch_start()
-    batch = tr.dummy_batch  # resident in HBM
+    def build_trainer(config, precision):
+        plans = trainer.make_plans(patch, STRIDES, batch_size=PER_GPU_BATCH * world)
+        if config in ("cfg2", "cfg5"):
+            t = trainer.nnUNetTrainerMI355Benchmark_noDataLoading(plans, "3d_fullres", 0, dataset_json(), device=dev)
+        else:
+            t = trainer.ContrastiveTrainerMI355(plans, "3d_fullres", 0, dataset_json(), device=dev)
+            t.use_topo = config == "cfg4"
+        if args.no_graph:
+            t.use_hip_graph = False
+        torch.manual_seed(0)
+        t.precision = precision
+        t.initialize()
+        if config in ("cfg3", "cfg4"):
+            t.dummy_batch = t.make_dummy_batch()
+        assert t.batch_size == PER_GPU_BATCH
+        t.on_train_epoch_start()
+        return t
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the roofline kernel's launches INSIDE the timed steps, bracketed by HIP events on the stream they run on (two event
-    # records per launch): fp32 = decoder stage 5 conv 0 forward (64 -> 32 at the patch), bf16 = the 32 -> 32 convs at the
-    # patch (encoder stage 0 conv 1, decoder stage 5 conv 1)
-    from multimodal_mvd_seg_amd import ops as _ops
-    bf = args.precision == "bf16"
-    timer = _ops.LaunchTimer((bf, PER_GPU_BATCH, 32, 0 if bf else 32, 32, *patch, (3, 3, 3), (1, 1, 1)))
-    _ops.LAUNCH_TIMER = timer
-    for _ in range(args.warmup):
-        tr.train_step(batch)
-    sync()
-    timer.on = not args.no_roofline
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = tr.train_step(batch)
-    sync()
-    dt = time.perf_counter() - t0
-    timer.on = False
-    _ops.LAUNCH_TIMER = None
+    def timed_steps(t, warmup, steps):
+        """`warmup` untimed steps (the first ones eager, then the capture of the step as a hipGraph and its first
+        replays), then EXACTLY `steps` timed steps between barrier + synchronize; returns (seconds, last step's output)."""
+        batch = t.dummy_batch  # resident in HBM
+        t.hip_graph_warmup = min(t.hip_graph_warmup, max(1, warmup - 1))  # capture inside the warm-up whenever W >= 2
+        for _ in range(warmup):
+            t.train_step(batch)
+        sync()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = t.train_step(batch)
+        sync()
+        return time.perf_counter() - t0, last
+
+    tr = build_trainer(args.config, args.precision)
+    dt, last = timed_steps(tr, args.warmup, args.steps)
+    graphed = tr._step_graph is not None and tr._step_graph.get("graph") is not None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # the roofline kernel's launches INSIDE train steps, bracketed by HIP events on the stream they run on (two event
+    # records per launch): fp32 = decoder stage 5 conv 0 forward (64 -> 32 at the patch), bf16 = the 32 -> 32 convs at the
+    # patch (encoder stage 0 conv 1, decoder stage 5 conv 1).  Events cannot be read inside a graph replay, so these are a
+    # few EAGER steps after the timed region (same kernels, same order).
+    from multimodal_mvd_seg_amd import ops as _ops
+    bf = args.precision == "bf16"
+    timer = _ops.LaunchTimer((bf, PER_GPU_BATCH, 32, 0 if bf else 32, 32, *patch, (3, 3, 3), (1, 1, 1)))
+    if not args.no_roofline and rank == 0 and world == 1:
+        was = tr.use_hip_graph
+        tr.use_hip_graph = False
+        _ops.LAUNCH_TIMER = timer
+        tr.train_step(tr.dummy_batch)
+        timer.on = True
+        for _ in range(5):
+            tr.train_step(tr.dummy_batch)
+        torch.cuda.synchronize()
+        timer.on = False
+        _ops.LAUNCH_TIMER = None
+        tr.use_hip_graph = was
 
     out = None
     if rank == 0:
@@ -374,14 +433,16 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16",
                "data": "synthetic",
                "config": {"workload": {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2] (dual-branch MVD step)",
-                                       "cfg4": "BASELINE configs[3] (dual-branch MVD step + soft-clDice)",
+                                       "cfg4": "BASELINE configs[3] (dual-branch MVD step + soft-clDice + component count)",
                                        "cfg5": "BASELINE configs[4]"}[args.config] +
                                       ": PlainConvUNet 3d_fullres 6 stages 31.2M params, "
                                       f"{IN_CH}x{'x'.join(map(str, patch))} patch, {NUM_CLASSES} classes, "
                                       f"{'fp32' if args.precision == 'fp32' else 'bf16 mixed precision'}, "
                                       "DC+CE deep supervision, SGD-Nesterov+clip",
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,
-                          "parallelism": f"dp{world}"},
+                          "parallelism": f"dp{world}",
+                          "step_launch": "one hipGraph replay per step (captured after 3 eager steps)" if graphed
+                                         else "eager (one launch per kernel)"},
                "final_loss": float(last["loss"])}
         if not args.no_roofline:
             out["roofline"] = in_step_roofline(roofline(), timer)
@@ -389,6 +450,21 @@ def main():
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(torch)
+    if rank == 0 and world == 1 and args.config == "cfg2" and args.precision == "fp32" and not args.no_secondary \
+            and tuple(patch) == PATCH:
+        # the same workload in bf16 mixed precision (the configuration north_star's 40 %-of-HBM block target is about):
+        # 10 warm-up + 20 timed steps, reported beside the fp32 line, never in its `value`
+        del tr
+        torch.cuda.empty_cache()
+        t16 = build_trainer("cfg2", "bf16")
+        dt16, last16 = timed_steps(t16, 10, 20)
+        sec = {"value": round(PER_GPU_BATCH * 20 / dt16, 3), "unit": "samples/s", "ms_per_step": round(dt16 / 20 * 1e3, 3),
+               "steps": 20, "warmup": 10, "dtype": "bf16", "final_loss": float(last16["loss"]),
+               "workload": "BASELINE configs[1] shape in bf16 mixed precision (bf16 activations on the bf16 MFMA engine, "
+                           "fp32 master weights / statistics / losses / optimizer)"}
+        if not args.no_roofline:
+            sec["roofline"] = bf16_block_roofline(torch, dev, patch)
+        out["secondary"] = {"bf16": sec}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

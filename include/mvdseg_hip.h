@@ -341,6 +341,12 @@ size_t mvd_sumsq_workspace_bytes(long n);
 int mvd_grad_sumsq(const float *g, float *out, long n, void *ws, size_t ws_bytes, void *stream);
 int mvd_sgd_nesterov_step(float *p, const float *g, float *buf, const float *sumsq, long n, float lr, float momentum,
                           float weight_decay, float max_norm, float grad_scale, int first_step, void *stream);
+/* the same step with its scalars read from a DEVICE array hyper[6] = {lr, momentum, weight_decay, max_norm, grad_scale,
+ * first_step (0/1)}: a hipGraph-captured train step (nnUNetTrainer.py:888-925 replayed as one graph launch) follows the
+ * PolyLR schedule (polylr.py:16-20, stepped per epoch :880) without re-capture.  sumsq must be given (max_norm <= 0 in
+ * hyper[3] switches clipping off). */
+int mvd_sgd_nesterov_step_dev(float *p, const float *g, float *buf, const float *sumsq, long n, const float *hyper,
+                              void *stream);
 
 /* misc elementwise helpers used by the host glue (all fixed-order / exact) */
 int mvd_nchw_to_ndhwc(const float *src, float *dst, int N, int C, long V, void *stream);

@@ -117,6 +117,7 @@ SIGNATURES = {
     "mvd_sumsq_workspace_bytes": (c_size_t, [c_long]),
     "mvd_grad_sumsq": (c_int, [_P, _P, c_long, _P, c_size_t, _P]),
     "mvd_sgd_nesterov_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "mvd_sgd_nesterov_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, _P]),
     "mvd_nchw_to_ndhwc": (c_int, [_P, _P, c_int, c_int, c_long, _P]),
     "mvd_pad_channels_bf16": (c_int, [_P, _P, c_int, c_int, c_int, c_long, c_int, _P]),
     "mvd_ndhwc_to_nchw": (c_int, [_P, _P, c_int, c_int, c_long, _P]),

@@ -32,9 +32,17 @@ __device__ inline float sgd_one(float &p, float g, float &b, float gscale, float
     return p;
 }
 
+// HYPER: the step's scalars come from a 6-float device array {lr, momentum, weight decay, max_norm, grad_scale, first step
+// (0/1)} instead of kernel arguments, so that a hipGraph-captured step follows the learning-rate schedule without
+// re-capture (nnUNetTrainerMI355's graphed train_step; PolyLR changes lr once per epoch, nnUNetTrainer.py:880)
+template <bool HYPER>
 __global__ void k_sgd(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf,
                       const float *__restrict__ sumsq, long n, float lr, float mom, float wd, float max_norm,
-                      float gscale, int first) {
+                      float gscale, int first, const float *__restrict__ hyper) {
+    if (HYPER) {
+        lr = hyper[0]; mom = hyper[1]; wd = hyper[2]; max_norm = hyper[3]; gscale = hyper[4];
+        first = hyper[5] != 0.f;
+    }
     float clip = 1.0f;
     if (max_norm > 0.f) {
         float total = sqrtf(sumsq[0]) * gscale;  // sumsq is over the un-scaled buffer
@@ -94,8 +102,19 @@ int mvd_sgd_nesterov_step(float *p, const float *g, float *buf, const float *sum
     MVD_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd_step: buffers must be 16-byte aligned");
     long bx = cdiv(n / 4 + 1, 256);
     if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(k_sgd, dim3(bx), dim3(256), 0, as_stream(stream), p, g, buf, sumsq, n, lr, momentum, weight_decay,
-                       max_norm, grad_scale, first_step);
+    hipLaunchKernelGGL(k_sgd<false>, dim3(bx), dim3(256), 0, as_stream(stream), p, g, buf, sumsq, n, lr, momentum,
+                       weight_decay, max_norm, grad_scale, first_step, (const float *)nullptr);
     return check_launch("sgd_step");
+}
+
+int mvd_sgd_nesterov_step_dev(float *p, const float *g, float *buf, const float *sumsq, long n, const float *hyper,
+                              void *stream) {
+    MVD_REQUIRE(p && g && buf && sumsq && hyper && n > 0, "sgd_step_dev: bad arguments");
+    MVD_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd_step_dev: buffers must be 16-byte aligned");
+    long bx = cdiv(n / 4 + 1, 256);
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(k_sgd<true>, dim3(bx), dim3(256), 0, as_stream(stream), p, g, buf, sumsq, n, 0.f, 0.f, 0.f, 0.f, 0.f, 0,
+                       hyper);
+    return check_launch("sgd_step_dev");
 }
 }

@@ -129,12 +129,14 @@ def pack_weight(weight, transposed):
 
 # ---------------------------------------------------------------------------------------------- packed-weight cache (fp32)
 # The packed copies (wf / wb, Winograd uf / ub) of a conv weight live on the weight tensor object (`_mvd_pack`) and are
-# valid for one stamp = (pack epoch, version of the parameter, storage pointer, version of the flat buffer the parameter
-# is a view of).  torch in-place writes to the parameter or to optim.FlatParams.flat (dist.broadcast, `flat -= ...`) bump
-# a version; the fused optimizer -- which updates the flat buffer through a raw pointer -- bumps the epoch and re-packs
-# every registered weight in ONE launch (repack_all: mvd_pack_weights_batch).  A stale or missing entry is packed on the
-# spot by the per-layer entries.  The one write torch cannot see is `p.data.copy_()` / any other raw-pointer writer:
-# such code must call invalidate_packs() (FlatParams.invalidate_packs).
+# valid for one stamp = (global pack epoch, epoch of the flat buffer the parameter is a view of, version of the parameter,
+# storage pointer, version of that flat buffer).  torch in-place writes to the parameter or to optim.FlatParams.flat
+# (dist.broadcast, `flat -= ...`) bump a version; the fused optimizer -- which updates ITS flat buffer through a raw
+# pointer -- bumps that buffer's epoch and re-packs the weights that live in it in ONE launch (repack_all(fp):
+# mvd_pack_weights_batch); the weights of another optimizer in the process are not touched (round 3: they used to be
+# re-packed and their saved graphs invalidated too).  A stale or missing entry is packed on the spot by the per-layer
+# entries.  The one write torch cannot see is `p.data.copy_()` / any other raw-pointer writer: such code must call
+# invalidate_packs() (FlatParams.invalidate_packs), which bumps the global epoch.
 _PACK_EPOCH = [0]
 _PACK_LIVE = []
 _PACK16_LIVE = []
@@ -158,10 +160,16 @@ class _PackEntry:
     __slots__ = ("transposed", "K", "C", "T", "wf", "wb", "uf", "ub", "stamp", "gen")
 
 
+def _flat_of(w, owner=None):
+    return getattr(owner if owner is not None else w, "_mvd_flat", None)
+
+
 def _pack_stamp(w, owner=None):
     # data_ptr: `p.data = other` swaps the storage without a version bump on the parameter object
-    flat = getattr(owner if owner is not None else w, "_mvd_flat", None)
-    return (_PACK_EPOCH[0], w._version, w.data_ptr(), flat._version if flat is not None else -1)
+    flat = _flat_of(w, owner)
+    local = getattr(flat, "_mvd_epoch", None) if flat is not None else None
+    return (_PACK_EPOCH[0], local[0] if local is not None else 0, w._version, w.data_ptr(),
+            flat._version if flat is not None else -1)
 
 
 def _packed(weight, transposed, want_uf=False, want_ub=False):
@@ -217,26 +225,51 @@ def _packed(weight, transposed, want_uf=False, want_ub=False):
     return e
 
 
-def _repack_all_bf16():
-    """The bf16 packs of every live weight that has them, in one launch (mvd_pack_weights_bf16_batch) into views of ONE
-    fresh buffer per device: the tensors a graph saved for backward keep their old buffer alive, exactly as with the
-    per-layer packs (fresh tensors per stamp)."""
-    jobs, alive = [], []
-    for r in _PACK16_LIVE:
+def _live(refs, attr, fp):
+    """(weight, cache entry) of the live registered weights -- all of them, or those that are views of `fp`'s buffer."""
+    out, alive = [], []
+    for r in refs:
         w = r()
-        e = getattr(w, "_mvd_pack16", None) if w is not None else None
+        e = getattr(w, attr, None) if w is not None else None
         if e is None:
             continue
         alive.append(r)
+        if fp is None or _flat_of(w) is fp.flat:
+            out.append((w, e))
+    refs[:] = alive
+    return out
+
+
+def _repack_all_bf16(fp=None):
+    """The bf16 packs of the live weights (of `fp`, or all) that have them, in one launch (mvd_pack_weights_bf16_batch)
+    into views of ONE buffer per device.  Default: a FRESH buffer per call -- the tensors an autograd graph saved for
+    backward keep their old buffer alive, exactly as with the per-layer packs (fresh tensors per stamp).  With
+    `fp.pack16_inplace` (set by a trainer that replays its step as a hipGraph: the captured forward must read the addresses
+    the captured repack of the previous replay wrote) the buffer is owned by `fp`, persists and is rewritten in place;
+    `fp.pack16_gen` then guards saved autograd graphs the way the fp32 entries' generations do."""
+    jobs = []
+    for w, e in _live(_PACK16_LIVE, "_mvd_pack16", fp):
         d = w.detach()
         if d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.device == e[0][2]:
             jobs.append((d, e[0][1], w))
-    _PACK16_LIVE[:] = alive
+    inplace = fp is not None and getattr(fp, "pack16_inplace", False)
     for dev in {d.device for d, _, _w in jobs}:
         js = [j for j in jobs if j[0].device == dev]
         sizes = [d.numel() for d, _, _w in js]
         pad = lambda n: (n + 127) // 128 * 128  # 256-byte aligned views
-        buf = torch.empty((2 * sum(pad(n) for n in sizes),), dtype=BF16, device=dev)
+        total = 2 * sum(pad(n) for n in sizes)
+        buf = None
+        if inplace:
+            sig = (dev, tuple((id(w), n) for (_d, _t, w), n in zip(js, sizes)))
+            held = getattr(fp, "_pack16_buf", None)
+            if held is not None and held[0] == sig:
+                buf = held[1]
+                fp.pack16_gen[0] += 1
+            else:
+                buf = torch.empty((total,), dtype=BF16, device=dev)
+                fp._pack16_buf = (sig, buf)
+        if buf is None:
+            buf = torch.empty((total,), dtype=BF16, device=dev)
         views, o = [], 0
         for n in sizes:
             views.append((buf[o:o + n], buf[o + pad(n):o + pad(n) + n]))
@@ -257,21 +290,46 @@ def _repack_all_bf16():
             w._mvd_pack16 = ((_pack_stamp(d, w), tr, d.device), v[0], v[1])
 
 
-def repack_all():
-    """Called by the fused optimizer after its update: new epoch, every live cached weight re-packed in one launch."""
-    _PACK_EPOCH[0] += 1
-    _repack_all_bf16()
-    jobs, alive = [], []
-    for r in _PACK_LIVE:
-        w = r()
-        e = getattr(w, "_mvd_pack", None) if w is not None else None
-        if e is None:
-            continue
-        alive.append(r)
+def _pack16_guard(weight):
+    """(generation holder, generation now) of the in-place bf16 packs `weight` takes part in, or None."""
+    flat = _flat_of(weight)
+    holder = getattr(flat, "_mvd_pack16_gen", None) if flat is not None else None
+    return (holder, holder[0]) if holder is not None else None
+
+
+def _check_pack16_generation(saved, what):
+    if saved is not None and saved[0][0] != saved[1]:
+        raise RuntimeError(f"{what}: the weights were updated (optimizer.step()) between the forward and the backward pass "
+                           "of this graph; the bf16 packed copies saved for backward were rewritten in place")
+
+
+def packs_stale(fp):
+    """True when a cached pack of one of `fp`'s weights no longer carries the current stamp (a torch-visible write, e.g.
+    load_state_dict, or invalidate_packs() since the last repack): a captured step, whose forward reads the persistent
+    pack buffers, must not be replayed before repack_all(fp) has refreshed them."""
+    for w, e in _live(_PACK_LIVE, "_mvd_pack", fp):
+        if e.stamp != _pack_stamp(w.detach(), w):
+            return True
+    for w, e in _live(_PACK16_LIVE, "_mvd_pack16", fp):
+        if e[0][0] != _pack_stamp(w.detach(), w):
+            return True
+    return False
+
+
+def repack_all(fp=None):
+    """Called by the fused optimizer after its update with its optim.FlatParams: new epoch of that flat buffer, every
+    live cached weight that is a view of it re-packed in one launch.  Without `fp`: every live weight of the process
+    (new global epoch)."""
+    if fp is None:
+        _PACK_EPOCH[0] += 1
+    else:
+        fp.flat._mvd_epoch[0] += 1
+    _repack_all_bf16(fp)
+    jobs = []
+    for w, e in _live(_PACK_LIVE, "_mvd_pack", fp):
         d = w.detach()
         if d.is_cuda and d.dtype == torch.float32 and d.is_contiguous() and d.device == e.wf.device:
             jobs.append((d, e, w))
-    _PACK_LIVE[:] = alive
     if not jobs:
         return
     if any(e.uf is not None or e.ub is not None for _, e, _w in jobs) and query("mvd_wino_mode") != 2:
@@ -411,6 +469,7 @@ class Conv3dFn(Function):
         ctx.bf = bf
         ctx.params = (weight, bias)
         ctx.pack = None if bf else (pk, pk.gen)
+        ctx.pack16_gen = _pack16_guard(weight) if bf else None
         ctx.save_for_backward(x1, x2, wb, ub)
         ctx.geom = (N, C1, C2, D, H, W, K, ks, tuple(stride), tuple(od), bias is not None)
         return y
@@ -419,7 +478,8 @@ class Conv3dFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x1, x2, wb, ub = ctx.saved_tensors
-        _check_pack_generation(ctx.pack, "conv3d backward")  # (the bf16 packs are fresh tensors per stamp)
+        _check_pack_generation(ctx.pack, "conv3d backward")  # (the bf16 packs are fresh tensors per stamp, or guarded:)
+        _check_pack16_generation(ctx.pack16_gen, "conv3d backward")
         N, C1, C2, D, H, W, K, ks, stride, od, has_bias = ctx.geom
         dy = to_ndhwc(dy)
         dev = dy.device
@@ -555,6 +615,7 @@ class ConvTranspose3dFn(Function):
         ctx.bf = bf
         ctx.params = (weight, bias)
         ctx.pack = None if bf else (pk, pk.gen)
+        ctx.pack16_gen = _pack16_guard(weight) if bf else None
         call("mvd_convT3d_fwd_bf16" if bf else "mvd_convT3d_fwd", _p(x), _p(wf), _p(bias), _p(y), N, D, H, W, C, K, i3(stride), _p(ws), ws.numel(),
              _stream())
         ctx.save_for_backward(x, wb)
@@ -566,6 +627,7 @@ class ConvTranspose3dFn(Function):
     def backward(ctx, dy):
         x, wb = ctx.saved_tensors
         _check_pack_generation(ctx.pack, "convT3d backward")
+        _check_pack16_generation(ctx.pack16_gen, "convT3d backward")
         N, C, K, D, H, W, stride, has_bias = ctx.geom
         dy = to_ndhwc(dy)
         dev = dy.device

@@ -35,6 +35,14 @@ class FlatParams:
             off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        # packed-weight cache (ops.py): epoch of THIS buffer (bumped by the optimizer that updates it through a raw pointer),
+        # and -- when a trainer replays its step as a hipGraph -- bf16 packs kept in one persistent buffer owned by this
+        # object and rewritten in place, with a generation counter guarding autograd graphs saved across the rewrite
+        self.flat._mvd_epoch = [0]
+        self.pack16_inplace = False
+        self.pack16_gen = [0]
+        self.flat._mvd_pack16_gen = self.pack16_gen
+        self._pack16_buf = None
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         # direct gradient sink (ops.py): the HIP backward kernels write dW / dbias / dgamma / dbeta straight into this
         # buffer instead of returning fresh tensors that autograd would add into p.grad with one small torch kernel per
@@ -97,6 +105,7 @@ class FusedSGDNesterov:
         self.momentum_buffer = torch.zeros_like(self.fp.flat)
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._steps = 0
+        self.hyper = self._hyper_host = None   # device copy of the step's scalars (use_device_hyper: hipGraph mode)
         # data parallel: the all-reduce leaves the SUM over ranks in fp.grad; the mean (DDP semantics) is taken inside
         # the optimizer kernel (g * grad_scale) instead of one more pass over the gradient buffer
         self.grad_scale = 1.0
@@ -109,6 +118,33 @@ class FusedSGDNesterov:
         """Device scalar: the global gradient 2-norm of the last step (before clipping)."""
         return self.sumsq.sqrt() * self.grad_scale
 
+    def _hyper_values(self):
+        g = self.param_groups[0]
+        return (float(g['lr']), float(g['momentum']), float(g['weight_decay']), float(self.max_grad_norm or 0.0),
+                float(self.grad_scale), 1.0 if self._steps == 0 else 0.0)
+
+    def use_device_hyper(self):
+        """hipGraph mode (trainer.train_step replayed as one graph launch): the step reads lr / momentum / weight decay /
+        clip norm / grad_scale / first-step flag from a 6-float device array (mvd_sgd_nesterov_step_dev), refreshed by
+        sync_hyper() between replays, so the captured step follows the PolyLR schedule without re-capture."""
+        if self.hyper is None:
+            self.hyper = torch.zeros(6, dtype=torch.float32, device=self.fp.flat.device)
+            self._hyper_host = None
+        self.sync_hyper()
+
+    def sync_hyper(self):
+        """Host -> device copy of the step's scalars when one of them changed (outside a capture: once per epoch)."""
+        if self.hyper is None:
+            return
+        v = self._hyper_values()
+        if v != self._hyper_host:
+            self.hyper.copy_(torch.tensor(v, dtype=torch.float32))
+            self._hyper_host = v
+
+    def note_replayed_step(self):
+        """A graph replay ran the captured step(): keep the host-side step counter (state_dict, first-step flag) true."""
+        self._steps += 1
+
     def step(self):
         fp, g = self.fp, self.param_groups[0]
         if not g['params'][0].is_cuda:
@@ -118,14 +154,20 @@ class FusedSGDNesterov:
         dev = fp.flat.device
         ws = ops._Workspace.get(query("mvd_sumsq_workspace_bytes", n), dev)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
-        if self.max_grad_norm and self.max_grad_norm > 0:
+        if (self.max_grad_norm and self.max_grad_norm > 0) or self.hyper is not None:
             call("mvd_grad_sumsq", P(fp.grad), P(self.sumsq), n, P(ws), ws.numel(), s)
-        call("mvd_sgd_nesterov_step", P(fp.flat), P(fp.grad), P(self.momentum_buffer), P(self.sumsq), n, float(g['lr']),
-             float(g['momentum']), float(g['weight_decay']), float(self.max_grad_norm or 0.0), float(self.grad_scale),
-             1 if self._steps == 0 else 0, s)
+        if self.hyper is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_hyper()
+            call("mvd_sgd_nesterov_step_dev", P(fp.flat), P(fp.grad), P(self.momentum_buffer), P(self.sumsq), n,
+                 P(self.hyper), s)
+        else:
+            call("mvd_sgd_nesterov_step", P(fp.flat), P(fp.grad), P(self.momentum_buffer), P(self.sumsq), n,
+                 float(g['lr']), float(g['momentum']), float(g['weight_decay']), float(self.max_grad_norm or 0.0),
+                 float(self.grad_scale), 1 if self._steps == 0 else 0, s)
         self._steps += 1
         # the update went through a raw pointer: new weight epoch + every cached packed weight rebuilt in one launch
-        ops.repack_all()
+        ops.repack_all(self.fp)
 
     def state_dict(self):
         return {'momentum_buffer': self.momentum_buffer.clone(), 'steps': self._steps,

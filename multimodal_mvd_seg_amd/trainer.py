@@ -14,6 +14,8 @@ are out of scope.
 `ContrastiveTrainerMI355` mirrors the dual-branch mutual-distillation step
 (nnUNet/nnunetv2/training/nnUNetTrainer/MVDTrainer.py:879-925; lambdas :132-134).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -153,6 +155,10 @@ class nnUNetTrainerMI355(object):
         self.ddp_bucket_bytes = 25 * 1024 * 1024  # DDP's default bucket_cap_mb (nnUNetTrainer.py:222 passes none)
         self.was_initialized = False
         self.batch_size = None
+        # train_step replayed as one hipGraph launch after `hip_graph_warmup` eager steps (MVD_HIPGRAPH=0: always eager)
+        self.use_hip_graph = os.environ.get("MVD_HIPGRAPH", "1") != "0"
+        self.hip_graph_warmup = 3
+        self._step_graph = None
 
     # -- plugin surface -------------------------------------------------------------------------------------
     @staticmethod
@@ -172,6 +178,8 @@ class nnUNetTrainerMI355(object):
                                                        self.enable_deep_supervision).to(self.device)
         set_precision(self.network, self.precision)
         self.optimizer, self.lr_scheduler = self.configure_optimizers()
+        if self.use_hip_graph:
+            self.optimizer.fp.pack16_inplace = True   # the captured repack rewrites the buffers the captured forward reads
         if self.is_ddp:
             # DDP(network): broadcast rank 0's weights, then reduce gradients bucket-wise during backward (:220-222)
             broadcast_parameters(self.optimizer.fp)
@@ -238,6 +246,87 @@ class nnUNetTrainerMI355(object):
         output = self.network(data)
         return self.loss(output, target), output
 
+    def _step_body(self, data, target):
+        """zero_grad -> forward -> loss -> backward -> (gradient all-reduce fence) -> clip + SGD (:901-924)."""
+        if self.reducer is not None:
+            self.reducer.reset()   # a backward() that raised last step must not leave stale bucket state behind
+        self.optimizer.zero_grad(set_to_none=True)
+        l, _ = self._forward_loss(data, target)
+        l.backward()
+        if self.reducer is not None:
+            self.reducer.wait()
+        self.optimizer.step()  # clip_grad_norm_(12) + SGD fused, clip coefficient stays on the device
+        return l.detach()
+
+    # -- the step as ONE hipGraph launch --------------------------------------------------------------------------
+    # The ~400 kernels of a step are enqueued by Python in 11-12 ms; the bf16 step needs 13 ms of device time and the
+    # reference's per-step `loss.cpu()` (:925) keeps the host from running ahead, so the device idles ~1.5 ms per step
+    # between launches (profiles/r02_bf16_step_per_launch.txt: span - sum of durations).  After `hip_graph_warmup` eager
+    # steps the step body is captured once per input geometry (torch.cuda.graph = hipGraph on ROCm) and replayed:
+    # identical kernels, arguments and order -> results bit-identical to the eager step (tests/test_gpu_graph.py).
+    # What keeps that valid: inputs are copied into static buffers; the optimizer's scalars live in device memory
+    # (mvd_sgd_nesterov_step_dev: PolyLR needs no re-capture); the packed weight copies are rewritten in place by the
+    # captured repack (FlatParams.pack16_inplace); nothing in the body synchronises or depends on host-side data.
+    def _graph_allowed(self):
+        if not self.use_hip_graph:
+            return False
+        if self.reducer is not None and self.reducer.world > 1:
+            # collectives inside a capture: RCCL supports it, but it is unverified here on more than one GPU
+            return os.environ.get("MVD_HIPGRAPH_DDP", "0") == "1" and dist.get_backend() == "nccl"
+        return True
+
+    def _graph_key(self, data, target):
+        tl = target if isinstance(target, (list, tuple)) else [target]
+        return (tuple(data.shape), data.dtype, tuple((tuple(t.shape), t.dtype) for t in tl), isinstance(target, list),
+                self.precision, self.network.training, self._graph_flags())
+
+    def _graph_flags(self):
+        return (bool(self.network.decoder.deep_supervision),)
+
+    def _graphed_step(self, data, target):
+        key = self._graph_key(data, target)
+        sg = self._step_graph
+        if sg is None or sg['key'] != key:
+            sg = self._step_graph = {'key': key, 'graph': None, 'warm': 0}
+        if sg['graph'] is None:
+            if sg['warm'] < self.hip_graph_warmup:
+                sg['warm'] += 1   # eager first: allocator steady state, the optimizer's first-step flag, pack caches
+                return self._step_body(data, target)
+            sg['data'] = data.clone()
+            sg['target'] = [t.clone() for t in target] if isinstance(target, list) else target.clone()
+            self.optimizer.use_device_hyper()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    sg['loss'] = self._step_body(sg['data'], sg['target'])
+            except Exception as e:  # leave the eager path intact and say so (no silent slow path)
+                self.use_hip_graph = False
+                self._step_graph = None
+                torch.cuda.synchronize()
+                import warnings
+                warnings.warn(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eagerly")
+                return self._step_body(data, target)
+            sg['graph'] = g
+            captured_now = True    # (the capture ran the body's Python once: the optimizer's step counter already moved)
+        else:
+            captured_now = False
+            if sg['data'].data_ptr() != data.data_ptr():
+                sg['data'].copy_(data, non_blocking=True)
+            if isinstance(target, list):
+                for st, t in zip(sg['target'], target):
+                    if st.data_ptr() != t.data_ptr():
+                        st.copy_(t, non_blocking=True)
+            elif sg['target'].data_ptr() != target.data_ptr():
+                sg['target'].copy_(target, non_blocking=True)
+        self.optimizer.sync_hyper()
+        if ops.packs_stale(self.optimizer.fp):   # load_state_dict / invalidate_packs since the last step: the captured
+            ops.repack_all(self.optimizer.fp)    # forward reads the persistent pack buffers -> refresh them first
+        sg['graph'].replay()
+        if not captured_now:
+            self.optimizer.note_replayed_step()
+        return sg['loss']
+
     def train_step(self, batch: dict, return_device_loss: bool = False) -> dict:
         data, target = batch['data'], batch['target']
         data = data.to(self.device, non_blocking=True)
@@ -245,15 +334,10 @@ class nnUNetTrainerMI355(object):
             target = [i.to(self.device, non_blocking=True) for i in target]
         else:
             target = target.to(self.device, non_blocking=True)
-        self.optimizer.zero_grad(set_to_none=True)
-        l, _ = self._forward_loss(data, target)
-        l.backward()
-        if self.reducer is not None:
-            self.reducer.wait()
-        self.optimizer.step()  # clip_grad_norm_(12) + SGD fused, clip coefficient stays on the device
+        l = self._graphed_step(data, target) if self._graph_allowed() else self._step_body(data, target)
         if return_device_loss:
-            return {'loss': l.detach()}
-        return {'loss': l.detach().cpu().numpy()}  # the reference syncs here every step (:925)
+            return {'loss': l}
+        return {'loss': l.cpu().numpy()}  # the reference syncs here every step (:925)
 
     def validation_step(self, batch: dict) -> dict:
         data, target = batch['data'], batch['target']
@@ -300,6 +384,8 @@ class ContrastiveTrainerMI355(nnUNetTrainerMI355):
         self.lambda1, self.lambda2, self.lambda3 = 0.5, 0.1, 1  # MVDTrainer.py:132-134
         self.vessel_channel = 2                                 # :897-898, :907-908
         self.use_topo, self.skel_iter, self.feat_kl, self.kl_T = True, 3, True, 1
+        self.topo_cc = True          # with use_topo: the integer connected-component count beside the soft-clDice term
+        self.last_topology = None
 
     @staticmethod
     def build_network_architecture(plans_manager, dataset_json, configuration_manager, num_input_channels,
@@ -328,4 +414,24 @@ class ContrastiveTrainerMI355(nnUNetTrainerMI355):
             prob = ops.SoftmaxSelectFn.apply(top1, v)
             tmask = ops.label_mask(tgt0, v).reshape(prob.shape)
             l = l + self.lambda3 * losses.soft_cldice(prob, tmask, self.skel_iter)
+            if self.topo_cc:
+                self.last_topology = self._component_counts(prob.detach(), tmask)
         return l, o1
+
+    def _component_counts(self, prob, tmask):
+        """The integer topology step of configs[3] ("cfg 3 + soft-clDice + CC count"; the reference's
+        per-step cubical-complex pass MVDTrainer.py:907-923 runs on the CPU): number of connected components (= Betti-0,
+        26-connectivity: voxels as closed top-dimensional cells) of the predicted vessel mask {softmax >= 0.5} and of the
+        label's vessel mask, per sample, on the device (mvd_cc_label: union-find, bit-exact against oracle/cc_oracle.c).
+        Stays on the device (no sync): {'cc_pred', 'cc_true', 'betti0_error'} int32 [N]."""
+        N = prob.shape[0]
+        cp, ct = [], []
+        for n in range(N):
+            cp.append(ops.cc_label(ops.threshold_mask(prob[n, 0], 0.5, ge=True), 26)[1])
+            ct.append(ops.cc_label(ops.threshold_mask(tmask[n, 0], 0.5, ge=True), 26)[1])
+        cp, ct = torch.cat(cp), torch.cat(ct)
+        return {'cc_pred': cp, 'cc_true': ct, 'betti0_error': (cp - ct).abs()}
+
+    def _graph_flags(self):
+        return (bool(self.network.do_ds), self.use_topo, self.topo_cc, self.skel_iter, self.feat_kl, self.kl_T,
+                self.lambda1, self.lambda3, self.vessel_channel)

@@ -19,20 +19,17 @@ class _FakeTimer:
         return self._ms if self.pairs else None
 
 
-def test_in_step_roofline_rescales_every_rate_by_the_same_factor():
+def test_in_step_roofline_keeps_frac_on_the_isolated_launch_and_adds_the_in_step_view():
     import bench
     roof = {"bound": "mfma", "achieved": 80.0, "peak": 157.3, "unit": "TFLOP/s", "frac": round(80.0 / 157.3, 4),
-            "effective_tflops": 180.0, "effective_over_peak": round(180.0 / 157.3, 4), "ms_per_launch": 2.5,
-            "hbm_view": {"algorithmic_GB": 1.611, "achieved_GBps": 644.4, "frac_of_hbm_peak": 0.0806}}
-    out = bench.in_step_roofline(dict(roof, hbm_view=dict(roof["hbm_view"])), _FakeTimer(2.0, 50))
-    assert out["ms_per_launch"] == 2.0 and out["ms_per_launch_isolated"] == 2.5 and out["launches_timed_in_step"] == 50
-    assert abs(out["achieved"] - 100.0) < 1e-6 and abs(out["frac"] - round(100.0 / 157.3, 4)) < 1e-9
-    assert abs(out["effective_tflops"] - 225.0) < 1e-6
-    assert abs(out["hbm_view"]["achieved_GBps"] - 805.5) < 0.06
-    assert out["frac_isolated"] == roof["frac"]
-    # no launches timed (e.g. --no-roofline runs never reach this; a shape that does not occur): the object is unchanged
+            "effective_tflops": 180.0, "ms_per_launch": 2.5}
+    out = bench.in_step_roofline(dict(roof), _FakeTimer(2.0, 5))
+    assert out["ms_per_launch"] == 2.5 and out["frac"] == roof["frac"] and out["achieved"] == 80.0
+    assert out["ms_per_launch_in_step"] == 2.0 and out["launches_timed_in_step"] == 5
+    assert abs(out["achieved_in_step"] - 100.0) < 1e-6 and abs(out["frac_in_step"] - round(100.0 / 157.3, 4)) < 1e-9
+    # no launches timed (a shape that does not occur in the step): the object is unchanged
     same = bench.in_step_roofline(dict(roof), _FakeTimer(2.0, 0))
-    assert same["ms_per_launch"] == 2.5 and "ms_per_launch_isolated" not in same
+    assert same == roof
 
 
 def test_metric_names_follow_config_and_precision():
@@ -56,11 +53,18 @@ def test_bench_line_has_the_contract_keys_and_in_step_roofline():
     assert d["unit"] == "samples/s" and d["dtype"] == "f32" and d["scaling"] == "weak" and "workload" in d["config"]
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]  # batch 2 per GPU
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_launch", "ms_per_launch_isolated"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "ms_per_launch",
+              "ms_per_launch_in_step", "frac_in_step"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.0 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["launches_timed_in_step"] == 3  # one forward launch of the roofline layer per timed step
+    assert r["launches_timed_in_step"] == 5  # one forward launch of the roofline layer in each of the 5 eager steps
+    assert "hipGraph" in d["config"]["step_launch"]
+    s16 = d["secondary"]["bf16"]            # the default run appends the bf16 steps (never in `value`)
+    assert s16["dtype"] == "bf16" and s16["steps"] == 20 and s16["value"] > d["value"]
+    b = s16["roofline"]
+    assert b["bound"] == "hbm" and abs(b["frac"] - b["algorithmic_GB_per_launch"] / (b["block_ms"] * 1e-3) / 8000.0) < 2e-3
+    assert b["conv_only"]["ms_per_launch"] <= b["block_ms"]
 
 
 @pytest.mark.gpu
@@ -73,5 +77,7 @@ def test_bench_line_bf16_reports_the_hbm_roofline_of_the_block():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0.0 < r["frac"] < 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["launches_timed_in_step"] == 6  # the two 32 -> 32 forward launches at the patch, per timed step
-    assert abs(r["achieved"] - r["algorithmic_GB_per_launch"] / (r["ms_per_launch"] * 1e-3)) < 0.01 * r["achieved"]
+    assert r["launches_timed_in_step"] == 10  # the two 32 -> 32 forward launches at the patch, in 5 eager steps
+    # the BLOCK (conv + every InstanceNorm launch it needs) against the block's byte model; the conv alone beside it
+    assert abs(r["achieved"] - r["algorithmic_GB_per_launch"] / (r["block_ms"] * 1e-3)) < 0.01 * r["achieved"]
+    assert r["conv_only"]["ms_per_launch"] < r["block_ms"] and r["conv_only"]["frac"] > r["frac"]
