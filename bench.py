@@ -59,6 +59,26 @@ def time_kernel(fn, iters, torch):
     return e0.elapsed_time(e1) / iters
 
 
+def time_graphed(fn, iters, torch):
+    """Average duration (ms) of a multi-launch sequence `fn`, replayed as a hipGraph (how the train step runs it: no host
+    launch gaps between its kernels), HIP events around `iters` replays."""
+    fn()
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def in_step_roofline(roof, timer):
     """Adds the kernel's average launch duration INSIDE train steps (HIP events around its launches on the launch stream,
     ops.LaunchTimer, taken over a few EAGER steps run right after the timed region -- the timed region itself is replayed
@@ -124,11 +144,26 @@ def bf16_block_roofline(torch, dev, patch):
         call("mvd_conv3d_fwd_bf16", P(x), C, None, 0, P(wf), P(blk.conv.bias), P(y), N, D, H, W, K, i3((3, 3, 3)),
              i3((1, 1, 1)), P(ws), ws.numel(), s)
 
-    def block():
+    blk2 = network.ConvDropoutNormReLU(nn.Conv3d, K, K, 3, 1, True, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, None,
+                                       None, nn.LeakyReLU, {'inplace': True}).to(dev)
+    blk2.precision = "bf16"
+    with torch.no_grad():
+        blk2.conv.weight.normal_(0, 0.05)
+
+    def block():      # the block as the TRAIN STEP runs it: conv (+ statistics epilogue) -> finalize -> apply pass
         with torch.no_grad():
-            blk(x)
+            blk.norm_act(blk.conv_only(x))
+
+    with torch.no_grad():
+        y_raw = blk.conv_only(x)
+    fused_ok = ops.fused_norm_conv_ok(y_raw, blk2.conv.weight, blk2.stride)
+
+    def block_fused():  # the block as the INFERENCE forward runs it: the previous block's finalize + this conv with the
+        with torch.no_grad():  # InstanceNorm-apply + LeakyReLU in its loader and the statistics in its epilogue
+            blk2.forward_from_raw(blk, y_raw)
     ms = time_kernel(conv, 10, torch)
-    bms = time_kernel(block, 10, torch)
+    bms = time_graphed(block, 10, torch)
+    fms = time_graphed(block_fused, 10, torch) if fused_ok else None
     V = float(N * D * H * W)
     alg_bytes = (C + K) * V * 2.0
     flops = 2.0 * 27 * C * K * V
@@ -136,8 +171,9 @@ def bf16_block_roofline(torch, dev, patch):
     cgbs = alg_bytes / (ms * 1e-3) / 1e9
     traffic, tsrc = measured_traffic("traffic_bytes_per_launch_bf16")
     roof = {"kernel": f"fused block Conv3d 32->32 3x3x3 + InstanceNorm3d + LeakyReLU @{'x'.join(map(str, patch))} bf16, "
-                      "batch 2 (conv: z-marching 8x32 columns on v_mfma_f32_32x32x16_bf16, weights resident in accumulator "
-                      "registers, k_fwd16z; + every InstanceNorm launch of the block)",
+                      "batch 2, as the train step runs it: conv on v_mfma_f32_16x16x32_bf16 (z-marching 8x32 columns, weights "
+                      "resident in accumulator registers, InstanceNorm statistics in the epilogue: k_fwd16y) + the finalize "
+                      "launch + the apply pass",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_GB_per_launch": round(alg_bytes / 1e9, 4),
             "block_ms": round(bms, 4), "ms_per_launch": round(bms, 4),
@@ -147,6 +183,14 @@ def bf16_block_roofline(torch, dev, patch):
             "instnorm_ms": round(bms - ms, 4),
             "mfma_view": {"tflops": round(flops / (ms * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                           "frac": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "of": "conv launch"}}
+    if fms is not None:
+        fg = alg_bytes / (fms * 1e-3) / 1e9
+        roof["inference_form"] = {"block_ms": round(fms, 4), "achieved": round(fg, 1), "frac": round(fg / HBM_PEAK_GBS, 4),
+                                  "what": "the block boundary as the no-grad forward runs it (sliding-window inference): "
+                                          "finalize launch + conv with the producing block's InstanceNorm-apply + LeakyReLU "
+                                          "in its loader and its own statistics in the epilogue -- the activated tensor is "
+                                          "never written, exactly the byte model above.  Not the train step: the weight "
+                                          "gradient needs the activated tensor"}
     g, b = torch.ones(K, device=dev), torch.zeros(K, device=dev)
 
     def norm():

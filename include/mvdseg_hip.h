@@ -142,6 +142,44 @@ int mvd_conv3d_wgrad_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2
                           void *ws, size_t ws_bytes, void *stream);
 int mvd_convT3d_wgrad_bf16(const uint16_t *x, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W,
                            int C, int K, const int stride[3], void *ws, size_t ws_bytes, void *stream);
+/* The fused block of the north_star in bf16 -- Conv3d 3x3x3 -> InstanceNorm3d(affine) -> LeakyReLU
+ * (get_network_from_plans.py:41-44; block composition UNetDecoder.py:61-65 / PlainConvEncoder) -- on the z-marching
+ * conv kernel (3x3x3, stride 1, 32 -> 32 channels, large volumes):
+ *   mvd_conv3d_fwd_bf16_stats_tiles: tiles per sample the conv would emit statistics for (0: this shape runs on a kernel
+ *     without the epilogue; the caller then uses mvd_instnorm_lrelu_fwd_bf16).
+ *   mvd_conv3d_fwd_bf16_fused: mvd_conv3d_fwd_bf16 plus
+ *     - tile_stats != NULL: per-workgroup (sum, sum of squares) of the bf16-rounded output per channel,
+ *       [N][*ntiles_out][K][2] floats (*ntiles_out = 0 on return: the kernel that ran has no epilogue);
+ *     - in_scale / in_shift != NULL ([N][C1] floats): the INPUT is the raw output of the producing conv and is
+ *       normalised + activated while it is staged, a = bf16(lrelu(fma(x, scale, shift))) with zero padding applied to a
+ *       -- the producing block's InstanceNorm-apply + LeakyReLU folded into this consumer's loader, so the activated
+ *       tensor is never written to HBM.  Error 3 when the shape does not take the z-marching kernel.
+ *   mvd_instnorm_finalize_tiles: tile statistics -> mean, rstd (biased variance, eps inside the root), scale = gamma*rstd,
+ *     shift = beta - mean*scale; one launch, fp64, fixed order.
+ *   mvd_instnorm_lrelu_apply_bf16: y = bf16(lrelu(fma(x, scale, shift))) -- the same arithmetic as the fused prologue, for
+ *     the consumers that have none.  The backward pass is mvd_instnorm_lrelu_bwd_bf16 on (x, mean, rstd). */
+int mvd_conv3d_fwd_bf16_stats_tiles(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
+                                    const int stride[3]);
+/* which z-marching kernel serves the 3x3x3 stride-1 convs with 32 produce channels at the patch resolution: 1 (default,
+ * MVD_FWD16Y) = k_fwd16y (16x16x32 tiles; 32 or 64 reduce channels; statistics epilogue and loader prologue), 0 =
+ * k_fwd16z (32x32x16 tiles, 32 reduce channels, loader prologue only).  A/B and cross-check switch. */
+int mvd_set_bf16_zmarch_kernel(int which);
+/* 1 when mvd_conv3d_fwd_bf16_fused accepts in_scale / in_shift for this shape (a kernel with the loader prologue runs it) */
+int mvd_conv3d_fwd_bf16_prologue_ok(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
+                                    const int stride[3]);
+int mvd_conv3d_fwd_bf16_fused(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *wf, const float *bias,
+                              uint16_t *y, int N, int D, int H, int W, int K, const int ksize[3], const int stride[3],
+                              const float *in_scale, const float *in_shift, float slope, float *tile_stats, int *ntiles_out,
+                              void *ws, size_t ws_bytes, void *stream);
+int mvd_instnorm_finalize_tiles(const float *tile_stats, long ntiles, const float *gamma, const float *beta, float *mean,
+                                float *rstd, float *scale, float *shift, int N, long V, int C, float eps, void *stream);
+int mvd_instnorm_lrelu_apply_bf16(const uint16_t *x, const float *scale, const float *shift, uint16_t *y, int N, long V,
+                                  int C, float slope, void *stream);
+/* statistics pass alone (for a conv whose kernel has no epilogue): mean, rstd and scale / shift of x (fp32 or bf16 NDHWC);
+ * workspace: mvd_instnorm_workspace_bytes */
+int mvd_instnorm_stats_bf16(const void *x, int x_is_bf16, const float *gamma, const float *beta, float *mean, float *rstd,
+                            float *scale, float *shift, int N, long V, int C, float eps, void *ws, size_t ws_bytes,
+                            void *stream);
 /* InstanceNorm+LeakyReLU with bf16 output (statistics and arithmetic fp32/fp64 as in the fp32 entry points).
  * x is fp32 (x_is_bf16 == 0: the first, fp32, conv of the network) or bf16; y and dy are bf16; dx has x's type.
  * Workspace: mvd_instnorm_workspace_bytes.  C % 4 == 0. */

@@ -334,8 +334,13 @@ static int run_wgrad(const WgradGeom &g, const float *a1, const float *a2, const
 }
 
 static int run_fwd16(const FwdGeom &g, const uint16_t *a1, const uint16_t *a2, const uint16_t *w, const float *bias,
-                     uint16_t *y1, uint16_t *y2, void *ws, size_t ws_bytes, hipStream_t s) {
-    int r = fwd_bf16(g, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+                     uint16_t *y1, uint16_t *y2, void *ws, size_t ws_bytes, hipStream_t s, const Fwd16Fuse *fuse = nullptr) {
+    int r = fwd_bf16(g, a1, a2, w, bias, y1, y2, ws, ws_bytes, s, fuse);
+    if (r < 0 && fuse && fuse->in_scale) {
+        set_error("bf16 conv engine: the fused InstanceNorm input prologue needs the z-marching kernel (3x3x3 stride 1, 32 -> 32 "
+                  "channels, >= 4 tiles per CU); C=%d+%d K=%d+%d", g.C1, g.C2, g.K1, g.K2);
+        return 3;
+    }
     if (r < 0) {
         set_error("bf16 conv engine: unsupported shape (needs C %% 32 == 0 and K %% 32 == 0; C=%d+%d K=%d+%d)", g.C1, g.C2,
                   g.K1, g.K2);
@@ -721,6 +726,54 @@ int mvd_conv3d_fwd_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2, 
     FwdGeom g;
     conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
     return run_fwd16(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+int mvd_set_bf16_zmarch_kernel(int which) {
+    if (which != 0 && which != 1) {
+        set_error("set_bf16_zmarch_kernel: 0 = k_fwd16z (32x32x16 tiles), 1 = k_fwd16y (16x16x32 tiles, InstanceNorm fusion)");
+        return 2;
+    }
+    fwd16y_enable(which);
+    return 0;
+}
+
+int mvd_conv3d_fwd_bf16_stats_tiles(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
+                                    const int stride[3]) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || K <= 0 || check_ks(ksize, stride, "conv3d_fwd_bf16_stats_tiles"))
+        return 0;
+    FwdGeom g;
+    conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    return fwd_bf16_stats_tiles(g);
+}
+
+int mvd_conv3d_fwd_bf16_prologue_ok(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
+                                    const int stride[3]) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || K <= 0 || check_ks(ksize, stride, "conv3d_fwd_bf16_prologue_ok"))
+        return 0;
+    FwdGeom g;
+    conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    return fwd_bf16_prologue_ok(g);
+}
+
+int mvd_conv3d_fwd_bf16_fused(const uint16_t *x1, int C1, const uint16_t *x2, int C2, const uint16_t *wf, const float *bias,
+                              uint16_t *y, int N, int D, int H, int W, int K, const int ksize[3], const int stride[3],
+                              const float *in_scale, const float *in_shift, float slope, float *tile_stats, int *ntiles_out,
+                              void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x1 && wf && y && C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "conv3d_fwd_bf16_fused: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_fwd_bf16_fused: bad shape");
+    MVD_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3d_fwd_bf16_fused: scale and shift come together");
+    MVD_REQUIRE(!tile_stats || ntiles_out, "conv3d_fwd_bf16_fused: tile_stats needs ntiles_out");
+    if (check_ks(ksize, stride, "conv3d_fwd_bf16_fused")) return 2;
+    FwdGeom g;
+    conv_fwd_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    Fwd16Fuse f;
+    f.tile_stats = tile_stats;
+    f.ntiles = ntiles_out;
+    f.in_scale = in_scale;
+    f.in_shift = in_shift;
+    f.slope = slope;
+    if (ntiles_out) *ntiles_out = 0;
+    return run_fwd16(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream), &f);
 }
 
 int mvd_conv3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, uint16_t *dx2, int C2, int N, int D, int H, int W,

@@ -1097,11 +1097,21 @@ __device__ inline unsigned cvt_pk_bf16(float a, float b) {  // one v_cvt_pk_bf16
 template <int R>
 struct ZIdx { static constexpr int value = R; };
 
-template <int DBG>
+// FUSE (round 3, the InstanceNorm fusion of the north_star's block): bit 0 = statistics epilogue -- every 16-byte chunk
+// of a finished output plane that passes through the store path (8 bf16 channels of one voxel per lane, the lane's
+// channel octet fixed) is also accumulated into per-lane (sum, sum of squares) registers; one cross-lane / cross-wave
+// combine at the end of the kernel writes the workgroup's partial [32 channels][2] (fixed order: deterministic).
+// bit 1 = input prologue -- the staged input is the RAW output of the producing conv and is normalised + activated
+// between the buffer load and the LDS write: a = bf16(lrelu(fma(x, scale[n][c], shift[n][c]))), zeros where the voxel
+// lies outside the volume (the zero padding applies to the activation).
+template <int DBG, int FUSE = 0>
 __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16ZTile tg, const unsigned short *__restrict__ a1,
                                                    const unsigned short *__restrict__ w, const float *__restrict__ bias,
-                                                   unsigned short *__restrict__ y1) {
-    constexpr int dbg = DBG;  // 1: no global loads / LDS writes after the prologue, 2: no MFMAs, 4: no stores, 8: no epilogue,
+                                                   unsigned short *__restrict__ y1, float *__restrict__ tile_stats,
+                                                   const float *__restrict__ in_scale, const float *__restrict__ in_shift,
+                                                   const float slope) {
+    constexpr int dbg = DBG;
+    constexpr bool PRO = (FUSE & 2) != 0;  // 1: no global loads / LDS writes after the prologue, 2: no MFMAs, 4: no stores, 8: no epilogue,
                               // 16: no barrier, 32: no A-fragment reads after the prologue, 64: descriptors not updated,
                               // 128: no buffer loads / stores issued, 256: no bias re-initialisation (ablation builds;
                               // results wrong)
@@ -1197,6 +1207,16 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
         voff[q] = (oh < g.Ho && ow < g.Wo) ? (unsigned)((oh * g.Wy + ow) * 64 + (lane & 3) * 16) : 0xfffffff0u;
     }
     asm volatile("" : "+v"(voff[0]), "+v"(voff[1]), "+v"(voff[2]), "+v"(voff[3]));
+    // FUSE: the lane's channel octet is fixed on both paths -- staging part tid & 3 (PRO), store chunk lane & 3 (ST)
+    float psc[PRO ? 8 : 1], psh[PRO ? 8 : 1];
+    if (PRO) {
+        const float *sp = in_scale + (size_t)n_ * 32 + (tid & 3) * 8, *tp = in_shift + (size_t)n_ * 32 + (tid & 3) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            psc[e] = sp[e];
+            psh[e] = tp[e];
+        }
+    }
     const size_t oplane = (size_t)g.Hy * g.Wy * 64;
     char *ybase = reinterpret_cast<char *>(y1) + (size_t)n_ * g.Dy * oplane;
     const char *abase = reinterpret_cast<const char *>(a1) + (size_t)n_ * g.Di * g.Hi * g.Wi * 64;
@@ -1215,17 +1235,37 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
                                                 live(j) ? (int)iplane32 : 0, 0x00020000);
     };
     auto stage_load = [&](int set, int u) { v[set][u] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)rel[u], 0, 0); };
-    auto stage_write = [&](int set, unsigned imgoff, int u) {
-        if (u < Z_XR - 1 || tid < Z_PARTS - (Z_XR - 1) * 256) *(lds_u4 *)(wa[u] + imgoff) = v[set][u];
+    // PRO: normalise + activate the staged 8 channels (4 VALU per element + one conversion per pair), zeros for parts
+    // outside the (y, x) plane or of a plane that does not exist (`lv`, block-uniform)
+    auto prologue = [&](u32x4 q, int u, bool lv) {
+        const bool ok = lv && rel[u] != 0xfffffff0u;
+        unsigned d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float lo = __uint_as_float(d[e] << 16), hi = __uint_as_float(d[e] & 0xffff0000u);
+            lo = __builtin_fmaf(lo, psc[2 * e], psh[2 * e]);
+            hi = __builtin_fmaf(hi, psc[2 * e + 1], psh[2 * e + 1]);
+            lo = fmaxf(lo, lo * slope);
+            hi = fmaxf(hi, hi * slope);
+            d[e] = ok ? cvt_pk_bf16(lo, hi) : 0u;
+        }
+        return u32x4{d[0], d[1], d[2], d[3]};
+    };
+    // (fused variants: slot = 64 u + tid / 4, so the swizzle bit (slot >> 3) & 1 does not depend on u and the LDS address of
+    // part u is wa[0] + 2048 u -- an immediate; five registers fewer)
+    auto stage_write = [&](int set, unsigned imgoff, int u, bool lv = true) {
+        const u32x4 q = PRO ? prologue(v[set][u], u, lv) : v[set][u];
+        const unsigned a_ = FUSE ? wa[0] + 2048u * u : wa[u];
+        if (u < Z_XR - 1 || tid < Z_PARTS - (Z_XR - 1) * 256) *(lds_u4 *)(a_ + imgoff) = q;
     };
     auto load_plane = [&](int set, int j) {
         set_in_plane(j);
 #pragma unroll
         for (int u = 0; u < Z_XR; u++) stage_load(set, u);
     };
-    auto store_plane = [&](int set, unsigned imgoff) {
+    auto store_plane = [&](int set, unsigned imgoff, bool lv) {
 #pragma unroll
-        for (int u = 0; u < Z_XR; u++) stage_write(set, imgoff, u);
+        for (int u = 0; u < Z_XR; u++) stage_write(set, imgoff, u, lv);
     };
     i32x4 af[3];  // ring of three A fragments, fetched two fragments ahead (also across planes)
     // fragment f = (r * 3 + dx) * 2 + ks of plane image IMG
@@ -1235,6 +1275,11 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
         af[BUF] = *reinterpret_cast<const i32x4 *>(&q_);                                                             \
     }
 
+    // (Statistics epilogue, FUSE bit 0: NOT in this kernel.  Measured in round 3 on three forms -- 16 running sums in VGPRs,
+    // transient sums aliased onto the dead accumulator set with AGPR-pinned totals, private LDS slots updated with
+    // ds_add_f32 -- the first two push staged input planes or weight fragments into scratch memory (the kernel runs at
+    // 254 + 236 of 512 registers), the third makes the launch seven times slower (1.47 ms: LDS float atomics).  The
+    // statistics epilogue lives in k_fwd16y, whose 16x16x32 tiling leaves a lane 4 channels instead of 16.)
     f32x16 S[4][2];  // accumulator ring: output plane zo lives in S[(zo - zb + 1) & 3]
     auto bias_init = [&](f32x16 &acc, int rg) {  // acc[4 rg .. 4 rg + 3] = bias
         const u32x4 q = *(lds_u4 *)(bsc + rg * 1024);
@@ -1242,7 +1287,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
         acc[rg * 4 + 2] = __uint_as_float(q.z); acc[rg * 4 + 3] = __uint_as_float(q.w);
     };
     load_plane(0, 0);
-    store_plane(0, 0);
+    store_plane(0, 0, live(0));
     load_plane(1, 1);
     load_plane(0, 2);
 #pragma unroll
@@ -1268,6 +1313,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
         constexpr int R = decltype(Rc)::value;
         constexpr int NEW = R, MID = (R + 3) & 3, OLD = (R + 2) & 3, DRN = (R + 1) & 3, RN = (R + 1) & 3;
         __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, 0, 0x00020000);
+        const bool lvn = live(j + 1);     // PRO: the plane written to LDS during this plane exists
         auto set_out_plane = [&]() {  // the plane held by DRN
             const int zo = zin(j) - 2;
             const bool st = zo >= zb && zo < ze && !(dbg & 4);
@@ -1312,7 +1358,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16z(const FwdGeom g, const Fwd16Z
                 constexpr int wslot[6] = {1, 2, 6, 9, 10, 14};
 #pragma unroll
                 for (int u = 0; u < 6; u++)
-                    if (f == wslot[u]) stage_write(RN & 1, IMGN, u);
+                    if (f == wslot[u]) stage_write(RN & 1, IMGN, u, lvn);
             }
             if (f == 4 && !(dbg & 64)) set_out_plane();
             if (f == 0 && !(dbg & 64)) set_next_in_plane();
@@ -1369,7 +1415,8 @@ static int num_cus16() {
 
 // -1: not this kernel's shape
 static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsigned short *w, const float *bias,
-                         unsigned short *y1, unsigned short *y2, hipStream_t s) {
+                         unsigned short *y1, unsigned short *y2, hipStream_t s, const Fwd16Fuse *fuse = nullptr,
+                         int *stats_tiles_only = nullptr) {
     static const int off = getenv("MVD_FWD16P") ? (atoi(getenv("MVD_FWD16P")) == 0) : 0;
     if (off) return -1;
     // 32 reduce channels; 32 produce channels, or 32 + 32 into two tensors (the input gradient of a conv that read two
@@ -1437,9 +1484,13 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
             tz.zc = (g.Do + best - 1) / best;
             tz.nzc = (g.Do + tz.zc - 1) / tz.zc;
             tz.nitems = (int)(cols * tz.nzc);
+            if (stats_tiles_only) {  // query: tiles per sample of the statistics epilogue (none here); 0 = this kernel runs
+                *stats_tiles_only = 0;
+                return 0;
+            }
             static const int dbgz = getenv("MVD_FWD16Z_DBG") ? atoi(getenv("MVD_FWD16Z_DBG")) & 1023 : 0;
             typedef void (*kz_t)(const FwdGeom, const Fwd16ZTile, const unsigned short *, const unsigned short *, const float *,
-                                 unsigned short *);
+                                 unsigned short *, float *, const float *, const float *, const float);
             kz_t kfn = k_fwd16z<0>;
             switch (dbgz) {
                 case 1: kfn = k_fwd16z<1>; break;
@@ -1456,26 +1507,36 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
                 case 1021: kfn = k_fwd16z<1021>; break;
                 default: break;
             }
-            static bool configured_z = false;
-            if (!configured_z) {
+            const bool want_stats = false;  // (k_fwd16y has the statistics epilogue)
+            const bool want_pro = fuse && fuse->in_scale && fuse->in_shift;
+            if (want_pro && two_out) return -1;
+            const int fz = (want_stats ? 1 : 0) | (want_pro ? 2 : 0);
+            if (fz == 2) kfn = k_fwd16z<0, 2>;
+            if (fuse && fuse->ntiles) *fuse->ntiles = want_stats ? tz.nzc * tz.nty * tz.ntx : 0;
+            static bool configured_z[4] = {false, false, false, false};
+            if (!configured_z[fz]) {
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z_LDS);
                 if (e != hipSuccess) {
                     set_error("conv fwd16z: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
                     return 1;
                 }
-                configured_z = true;
+                configured_z[fz] = true;
             }
             const int per_xcd = (tz.nitems + 7) / 8;
             tz.kp = g.K1 + g.K2;
             for (int q = 0; q < (two_out ? 2 : 1); q++) {
                 tz.koff = 32 * q;
-                hipLaunchKernelGGL(kfn, dim3((unsigned)(per_xcd * 8)), dim3(256), (size_t)Z_LDS, s, g, tz, a1, w, bias,
-                                   q ? y2 : y1);
+                hipLaunchKernelGGL(kfn, dim3((unsigned)(per_xcd * 8)), dim3(256), (size_t)Z_LDS, s, g,
+                                   tz, a1, w, bias, q ? y2 : y1, want_stats ? fuse->tile_stats : nullptr, want_pro ? fuse->in_scale : nullptr,
+                                   want_pro ? fuse->in_shift : nullptr, fuse ? fuse->slope : 0.f);
                 if (check_launch("conv fwd16z (z-marching bf16 mfma, weights in registers)")) return 1;
             }
             return 0;
         }
+        if (stats_tiles_only) { *stats_tiles_only = 0; return 1; }
+        if (fuse && fuse->in_scale) return -1;   // only the z-marching kernel has the input prologue
+        if (fuse && fuse->ntiles) *fuse->ntiles = 0;
         if (two_out) return -1;
         static const int use_r = getenv("MVD_FWD16R") ? atoi(getenv("MVD_FWD16R")) : 0;
         if (ok && use_r) {
@@ -1512,6 +1573,9 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
         }
     }
     if (two_out) return -1;
+    if (stats_tiles_only) { *stats_tiles_only = 0; return 1; }
+    if (fuse && fuse->in_scale) return -1;
+    if (fuse && fuse->ntiles) *fuse->ntiles = 0;
     const size_t lds = (size_t)P_WB + 2 * (size_t)P_HALO;
     static bool configured = false;
     if (!configured) {
@@ -1528,9 +1592,29 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
 }
 
 // returns 0 ok, >0 error, -1 unsupported shape
+int fwd_bf16_stats_tiles(const FwdGeom &g) {
+    int nt = 0;
+    if ((g.C1 + g.C2) % 32 || (g.K1 + g.K2) % 32) return 0;
+    if (launch_fwd16y(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (num_cus16() / 8) * 8, &nt) == 0)
+        return nt;
+    const int r = launch_fwd16p(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &nt);
+    return r == 0 ? nt : 0;
+}
+
+int fwd_bf16_prologue_ok(const FwdGeom &g) {  // 1: the shape runs on a kernel with the InstanceNorm input prologue
+    int nt = 0;
+    if ((g.C1 + g.C2) % 32 || (g.K1 + g.K2) % 32 || (g.K2 != 0)) return 0;
+    if (g.C1 == 32 && g.C2 == 0 &&
+        launch_fwd16y(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (num_cus16() / 8) * 8, &nt) == 0)
+        return 1;
+    return launch_fwd16p(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &nt) == 0 ? 1 : 0;
+}
+
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
-             const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s) {
+             const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s,
+             const Fwd16Fuse *fuse) {
     const int C = g.C1 + g.C2, K = g.K1 + g.K2;
+    if (fuse && fuse->ntiles) *fuse->ntiles = 0;
     if (g.ntaps < 1 || g.ntaps > 27) return -1;
     if (C % 32 != 0 || g.C1 % 32 != 0 || g.C2 % 32 != 0) return -1;
     if (K % 32 != 0 || g.K1 % 32 != 0 || g.K2 % 32 != 0) return -1;
@@ -1542,9 +1626,12 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
             if (g.off[t][a] > mx[a]) mx[a] = g.off[t][a];
         }
     {
-        int r = launch_fwd16p(g, a1, w, bias, y1, y2, s);
+        int r = launch_fwd16y(g, a1, a2, w, bias, y1, y2, s, fuse, (num_cus16() / 8) * 8, nullptr);
+        if (r >= 0) return r;
+        r = launch_fwd16p(g, a1, w, bias, y1, y2, s, fuse);
         if (r >= 0) return r;
     }
+    if (fuse && fuse->in_scale) return -1;  // the generic kernels have no input prologue
     const int NT = (K % 64 == 0) ? 2 : 1;
     auto magic = [](int d, int nmax) -> int {
         int m = (1 << 20) / d + 1;  // 20-bit reciprocal: n < 2048 keeps n*m inside int32

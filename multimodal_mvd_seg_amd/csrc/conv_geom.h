@@ -98,8 +98,32 @@ int convT_dgrad_direct16(const unsigned short *dy, const unsigned short *wb, uns
                          int C, int K, const int st[3], hipStream_t s);
 
 // bf16 forward-type engine (conv_bf16.hip): bf16 activations / packed weights, fp32 accumulate, bf16 output
+// Optional InstanceNorm fusion of the z-marching kernel k_fwd16z (get_network_from_plans.py:41-44: conv -> InstanceNorm3d
+// -> LeakyReLU): `tile_stats` != null asks for the per-workgroup (sum, sum of squares) of the bf16-rounded OUTPUT per
+// channel ([N][ntiles][K][2] floats; *ntiles is set to the tiles per sample, or to 0 when the kernel that ran cannot emit
+// them); `in_scale` / `in_shift` != null ([N][C1] floats) make the kernel normalise + activate its INPUT while staging it:
+// a = bf16(lrelu(fma(x, scale, shift))) -- the InstanceNorm-apply of the producing block folded into this consumer's
+// loader (zero padding applies to a, i.e. halo voxels outside the volume stay 0).  `required` = fail (-1) instead of
+// running un-fused when the shape does not take the z-marching kernel.
+struct Fwd16Fuse {
+    float *tile_stats = nullptr;
+    int *ntiles = nullptr;
+    const float *in_scale = nullptr, *in_shift = nullptr;
+    float slope = 0.01f;
+};
 int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
-             const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s);
+             const float *bias, unsigned short *y1, unsigned short *y2, void *ws, size_t ws_bytes, hipStream_t s,
+             const Fwd16Fuse *fuse = nullptr);
+int fwd16y_enabled();
+void fwd16y_enable(int on);
+// k_fwd16y (conv_bf16y.hip): -1 = not this kernel's shape; stats_tiles_only != null = query (no launch)
+int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w,
+                  const float *bias, unsigned short *y1, unsigned short *y2, hipStream_t s, const Fwd16Fuse *fuse, int ncu,
+                  int *stats_tiles_only);
+// tiles per sample the z-marching kernel would emit statistics for (0: this shape does not run on it)
+int fwd_bf16_stats_tiles(const FwdGeom &g);
+// 1 when the shape runs on a kernel that has the InstanceNorm input prologue (Fwd16Fuse::in_scale / in_shift)
+int fwd_bf16_prologue_ok(const FwdGeom &g);
 int pack_weight16(const float *w, unsigned short *wf, unsigned short *wb, int K, int C, int T, int transposed,
                   hipStream_t s);
 int pack_weights16_batch(int n, const float *const *w, unsigned short *const *wf, unsigned short *const *wb, const int *K,

@@ -445,6 +445,93 @@ __global__ void k_in_bwd_finalize(const double *__restrict__ partial, float *__r
     }
 }
 
+// conv-epilogue statistics of the bf16 z-marching conv (k_fwd16z<.., FUSE & 1>): per-workgroup partials [n][tile][C][2]
+// (fp32) -> mean, rstd and the fused form scale = gamma * rstd, shift = beta - mean * scale, ONE launch: a wave per
+// (n, c), lanes stride over the tiles, fp64, fixed shuffle tree (deterministic).
+__global__ void k_in_finalize_tiles(const float *__restrict__ tile, const float *__restrict__ gamma,
+                                    const float *__restrict__ beta, float *__restrict__ mean, float *__restrict__ rstd,
+                                    float *__restrict__ scale, float *__restrict__ shift, int C, long ntiles, long V,
+                                    float eps) {
+    const int n = blockIdx.y, c = blockIdx.x;
+    double a = 0, q = 0;
+    const float2 *tp = reinterpret_cast<const float2 *>(tile) + (size_t)n * ntiles * C + c;
+    long t = threadIdx.x;
+    for (; t + 192 < ntiles; t += 256) {  // four partials in flight per lane, added in tile order
+        const float2 v0 = tp[(size_t)t * C], v1 = tp[(size_t)(t + 64) * C], v2 = tp[(size_t)(t + 128) * C],
+                     v3 = tp[(size_t)(t + 192) * C];
+        a += (double)v0.x; q += (double)v0.y;
+        a += (double)v1.x; q += (double)v1.y;
+        a += (double)v2.x; q += (double)v2.y;
+        a += (double)v3.x; q += (double)v3.y;
+    }
+    for (; t < ntiles; t += 64) {
+        const float2 v = tp[(size_t)t * C];
+        a += (double)v.x;
+        q += (double)v.y;
+    }
+    a = wave_sum(a);
+    q = wave_sum(q);
+    if (threadIdx.x != 0) return;
+    const double m = a / (double)V;
+    double var = q / (double)V - m * m;
+    if (var < 0) var = 0;
+    const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+    const size_t nc = (size_t)n * C + c;
+    mean[nc] = mf;
+    rstd[nc] = rs;
+    const float sc = gamma[c] * rs;
+    scale[nc] = sc;
+    shift[nc] = fmaf(-mf, sc, beta[c]);
+}
+
+// y = bf16(lrelu(fma(x, scale[n][c], shift[n][c]))): the apply pass in the form the fused conv prologue uses (k_fwd16z<.., FUSE &
+// 2>), so that a tensor normalised here and one normalised in a consumer's loader agree bit for bit.  bf16 in, bf16 out.
+__global__ void k_in_apply_ss16(const unsigned short *__restrict__ x, const float *__restrict__ scale,
+                                const float *__restrict__ shift, unsigned short *__restrict__ y, int C, int CG, int R, long V,
+                                long chunk, float slope) {
+    const int n = blockIdx.y, t = threadIdx.x;
+    const int g = t % CG, r = t / CG;
+    if (r >= R) return;
+    const long v0 = (long)blockIdx.x * chunk;
+    long v1 = v0 + chunk;
+    if (v1 > V) v1 = V;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        sc[i] = scale[(size_t)n * C + g * 4 + i];
+        sh[i] = shift[(size_t)n * C + g * 4 + i];
+    }
+    const float *xf = reinterpret_cast<const float *>(x);
+    float *yf = reinterpret_cast<float *>(y);
+    const size_t base = ((size_t)n * V) * C + (size_t)g * 4;
+    long v = v0 + r;
+    for (; v + 3L * R < v1; v += 4L * R) {  // four independent rows in flight
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = ld4<true>(xf, base + (size_t)(v + (long)u * R) * C);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float f[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float z = fmaf(f[i], sc[i], sh[i]);
+                f[i] = fmaxf(z, z * slope);
+            }
+            st4<true>(yf, base + (size_t)(v + (long)u * R) * C, f[0], f[1], f[2], f[3]);
+        }
+    }
+    for (; v < v1; v += R) {
+        float4 q = ld4<true>(xf, base + (size_t)v * C);
+        float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float z = fmaf(f[i], sc[i], sh[i]);
+            f[i] = fmaxf(z, z * slope);
+        }
+        st4<true>(yf, base + (size_t)v * C, f[0], f[1], f[2], f[3]);
+    }
+}
+
 template <int VEC>
 __global__ void k_in_bwd_apply(const float *__restrict__ x, const float *__restrict__ dy,
                                const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -620,6 +707,67 @@ int mvd_instnorm_lrelu_fwd_prestats(const float *x, const float *tile_stats, lon
                                     float slope, void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(tile_stats && ntiles > 0, "instnorm_fwd_prestats: tile statistics required");
     return in_fwd(x, false, gamma, beta, y, false, mean, rstd, N, V, C, eps, slope, ws, ws_bytes, stream, tile_stats, ntiles);
+}
+
+int mvd_instnorm_finalize_tiles(const float *tile_stats, long ntiles, const float *gamma, const float *beta, float *mean,
+                                float *rstd, float *scale, float *shift, int N, long V, int C, float eps, void *stream) {
+    MVD_REQUIRE(tile_stats && gamma && beta && mean && rstd && scale && shift, "instnorm_finalize_tiles: null pointer");
+    MVD_REQUIRE(ntiles > 0 && N > 0 && N <= 65535 && V > 0 && C > 0 && C <= 65535, "instnorm_finalize_tiles: bad shape");
+    hipLaunchKernelGGL(k_in_finalize_tiles, dim3(C, N), dim3(64), 0, as_stream(stream), tile_stats, gamma, beta, mean, rstd,
+                       scale, shift, C, ntiles, V, eps);
+    return check_launch("instnorm finalize (conv tile statistics)");
+}
+
+// scale = gamma * rstd, shift = beta - mean * scale for [N][C] (the fused form of mean / rstd; same rounding as
+// k_in_finalize_tiles)
+__global__ void k_in_scale_shift(const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean,
+                                 const float *__restrict__ rstd, float *__restrict__ scale, float *__restrict__ shift, int N,
+                                 int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const float sc = gamma[i % C] * rstd[i];
+    scale[i] = sc;
+    shift[i] = fmaf(-mean[i], sc, beta[i % C]);
+}
+
+int mvd_instnorm_stats_bf16(const void *x, int x_is_bf16, const float *gamma, const float *beta, float *mean, float *rstd,
+                            float *scale, float *shift, int N, long V, int C, float eps, void *ws, size_t ws_bytes,
+                            void *stream) {
+    MVD_REQUIRE(x && gamma && beta && mean && rstd && scale && shift && ws, "instnorm_stats: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C % 4 == 0 && C <= 1024, "instnorm_stats: bad shape (C %% 4 == 0)");
+    MVD_REQUIRE(ws_bytes >= mvd_instnorm_workspace_bytes(N, V, C), "instnorm_stats: workspace too small");
+    NormGeom g = norm_geom(N, V, C);
+    MVD_REQUIRE(g.CG * 4 == C, "instnorm_stats: C too wide");
+    hipStream_t s = as_stream(stream);
+    double *partial = reinterpret_cast<double *>(ws);
+    const size_t sm = (size_t)g.R * C * 2 * sizeof(double);
+    MVD_REQUIRE(sm <= 64 * 1024, "instnorm_stats: C too large for the LDS reduce");
+    const float *xf = reinterpret_cast<const float *>(x);
+    if (x_is_bf16)
+        hipLaunchKernelGGL((k_in_stats<4, true>), dim3(g.nblk, N), dim3(g.threads), sm, s, xf, partial, C, g.CG, g.R, V, g.chunk);
+    else
+        hipLaunchKernelGGL((k_in_stats<4, false>), dim3(g.nblk, N), dim3(g.threads), sm, s, xf, partial, C, g.CG, g.R, V, g.chunk);
+    if (check_launch("instnorm stats")) return 1;
+    hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
+    if (check_launch("instnorm finalize")) return 1;
+    hipLaunchKernelGGL(k_in_scale_shift, dim3((N * C + 255) / 256), dim3(256), 0, s, gamma, beta, mean, rstd, scale, shift, N, C);
+    return check_launch("instnorm scale/shift");
+}
+
+int mvd_instnorm_lrelu_apply_bf16(const uint16_t *x, const float *scale, const float *shift, uint16_t *y, int N, long V,
+                                  int C, float slope, void *stream) {
+    MVD_REQUIRE(x && scale && shift && y, "instnorm_apply_bf16: null pointer");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C % 4 == 0 && C <= 1024, "instnorm_apply_bf16: bad shape (C %% 4 == 0)");
+    NormGeom g = norm_geom(N, V, C);
+    MVD_REQUIRE(g.CG * 4 == C, "instnorm_apply_bf16: C too wide");
+    long nb2 = V / ((long)g.R * 8);
+    if (nb2 < 1) nb2 = 1;
+    long cap2 = 8192 / N > 0 ? 8192 / N : 1;
+    if (nb2 > cap2) nb2 = cap2;
+    const long chunk2 = cdiv(V, nb2);
+    hipLaunchKernelGGL(k_in_apply_ss16, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, as_stream(stream), x, scale,
+                       shift, y, C, g.CG, g.R, V, chunk2, slope);
+    return check_launch("instnorm apply (scale / shift form)");
 }
 
 int mvd_instnorm_lrelu_fwd_bf16(const void *x, int x_is_bf16, const float *gamma, const float *beta, uint16_t *y,

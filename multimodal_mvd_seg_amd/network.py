@@ -8,6 +8,7 @@ torch.nn layer types only so that parameter registration, `state_dict()` keys, `
 (network_initialization.py:4-12, which dispatches on isinstance(nn.Conv3d / nn.ConvTranspose3d)) and DDP-style
 parameter handling behave exactly like the reference's modules.
 """
+import os
 from typing import List, Sequence, Tuple, Type, Union
 
 import numpy as np
@@ -15,6 +16,12 @@ import torch
 from torch import nn
 
 from . import ops
+
+
+# InstanceNorm-apply + LeakyReLU in the consumer conv's loader (bf16, z-marching kernel): on in inference; under autograd
+# only on request (the weight gradient needs the activated tensor and re-materialises it)
+FUSE_PROLOGUE = [os.environ.get("MVD_FUSE_PROLOGUE", "1") != "0"]
+FUSE_PROLOGUE_TRAIN = [os.environ.get("MVD_FUSE_PROLOGUE_TRAIN", "0") == "1"]
 
 
 def _tup3(v):
@@ -86,17 +93,28 @@ class ConvDropoutNormReLU(nn.Module):
         self.all_modules = nn.Sequential(self.conv, self.norm, self.nonlin)
         self.precision = "fp32"  # "bf16": see set_precision()
 
-    def forward(self, x, x2=None):
+    def conv_only(self, x, x2=None):
+        """The block's convolution alone (raw output; in bf16 with the InstanceNorm statistics from the conv's epilogue
+        attached when the kernel emits them)."""
         cw = self.conv.weight
         if (self.precision == "bf16" and x2 is None and x.dtype == torch.float32 and x.shape[1] <= 8 and
                 cw.shape[0] % 32 == 0 and tuple(cw.shape[2:]) == (3, 3, 3) and self.stride == (1, 1, 1) and x.is_cuda):
             # the 4-modality input layer under mixed precision: bf16 operands like every other conv of the net
-            y = ops.NarrowInputConv3dBf16Fn.apply(x, cw, self.conv.bias)
-        else:
-            y = self.conv(x, x2)
+            return ops.NarrowInputConv3dBf16Fn.apply(x, cw, self.conv.bias)
+        return self.conv(x, x2)
+
+    def norm_act(self, y):
         return ops.InstanceNormLeakyReLUFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps,
-                                                 self.nonlin.negative_slope,
-                                                 self.precision == "bf16")
+                                                 self.nonlin.negative_slope, self.precision == "bf16")
+
+    def forward(self, x, x2=None):
+        return self.norm_act(self.conv_only(x, x2))
+
+    def forward_from_raw(self, prev, y_raw):
+        """This block's conv fed with the RAW conv output of the previous block `prev`: prev's InstanceNorm + LeakyReLU run
+        inside this conv's loader (ops.NormActConv3dFn).  Returns this block's raw conv output."""
+        return ops.NormActConv3dFn.apply(y_raw, prev.norm.weight, prev.norm.bias, prev.norm.eps,
+                                         prev.nonlin.negative_slope, self.conv.weight, self.conv.bias)
 
     def compute_conv_feature_map_size(self, input_size):
         output_size = [i // j for i, j in zip(input_size, self.stride)]
@@ -121,9 +139,38 @@ class StackedConvBlocks(nn.Module):
         self.initial_stride = _tup3(initial_stride)
 
     def forward(self, x, x2=None):
-        for i, blk in enumerate(self.convs):
-            x = blk(x, x2) if i == 0 else blk(x)
+        """conv -> norm -> act per block.  bf16 mixed precision, consecutive blocks whose second conv takes the z-marching
+        kernel (3x3x3, stride 1, 32 -> 32 channels at the patch resolution): the first block's InstanceNorm + LeakyReLU is
+        folded into the second conv's loader (no apply pass, the activated tensor is never written) -- in inference
+        (no autograd), or under autograd with MVD_FUSE_PROLOGUE_TRAIN=1 (there the weight gradient re-materialises it)."""
+        blocks = list(self.convs)
+        raw = None   # the raw conv output of the previous block when its norm + act are still pending
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            fuse_next = nxt is not None and self._can_fuse(blk, nxt, x if raw is None else raw)
+            if raw is None and not fuse_next:
+                x = blk(x, x2) if i == 0 else blk(x)      # the plain module call (forward hooks fire)
+                continue
+            y = blk.forward_from_raw(blocks[i - 1], raw) if raw is not None else \
+                (blk.conv_only(x, x2) if i == 0 else blk.conv_only(x))
+            if fuse_next and ops.fused_norm_conv_ok(y, nxt.conv.weight, nxt.stride):
+                raw = y
+                continue
+            raw = None
+            x = blk.norm_act(y)
         return x
+
+    @staticmethod
+    def _can_fuse(blk, nxt, inp):
+        """Shape-only test (before anything runs) whether blk's InstanceNorm + LeakyReLU can ride in nxt's conv loader."""
+        if not (blk.precision == "bf16" and FUSE_PROLOGUE[0] and (not torch.is_grad_enabled() or FUSE_PROLOGUE_TRAIN[0])):
+            return False
+        w = nxt.conv.weight
+        if tuple(w.shape[2:]) != (3, 3, 3) or nxt.stride != (1, 1, 1) or w.shape[1] != blk.output_channels or not inp.is_cuda:
+            return False
+        sp = [(d + 2 * ((k - 1) // 2) - k) // st + 1 for d, k, st in zip(inp.shape[2:], blk.conv.kernel_size, blk.stride)]
+        return ops.query("mvd_conv3d_fwd_bf16_prologue_ok", inp.shape[0], sp[0], sp[1], sp[2], blk.output_channels, 0,
+                         w.shape[0], ops.i3((3, 3, 3)), ops.i3((1, 1, 1))) > 0
 
     def compute_conv_feature_map_size(self, input_size):
         output = self.convs[0].compute_conv_feature_map_size(input_size)

@@ -5,6 +5,7 @@ arithmetic operation of the hot path runs in libmvdseg_hip.so.  Activations are 
 [N,C,D,H,W] stored NDHWC (torch.channels_last_3d); logits / targets / volumes of the topology losses are planar.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -408,6 +409,28 @@ class LaunchTimer:
 LAUNCH_TIMER = None
 
 
+BF16_CONV_STATS = [os.environ.get("MVD_BF16_CONV_STATS", "1") != "0"]
+
+
+def conv3d_fwd_bf16(x1, C1, x2, C2, wf, bias, y, N, D, H, W, K, ks, stride, ws, in_scale=None, in_shift=None, slope=0.01):
+    """mvd_conv3d_fwd_bf16, through the fused entry when the z-marching kernel takes the shape: the InstanceNorm
+    statistics of the output then come out of the conv's epilogue (attached to `y` as `_mvd_tile_stats16`, picked up by
+    InstanceNormLeakyReLUFn / NormActConv3dFn) and, with in_scale / in_shift, the input is normalised + activated in the
+    loader (mvd_conv3d_fwd_bf16_fused)."""
+    nt = query("mvd_conv3d_fwd_bf16_stats_tiles", N, D, H, W, C1, C2, K, i3(ks), i3(stride)) \
+        if (BF16_CONV_STATS[0] or in_scale is not None) else 0
+    if nt <= 0 and in_scale is None:
+        call("mvd_conv3d_fwd_bf16", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
+             _p(ws), ws.numel(), _stream())
+        return
+    stats = torch.empty((N, nt, K, 2), dtype=torch.float32, device=y.device) if (nt > 0 and BF16_CONV_STATS[0]) else None
+    got = ctypes.c_int(0)
+    call("mvd_conv3d_fwd_bf16_fused", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
+         _p(in_scale), _p(in_shift), float(slope), _p(stats), ctypes.byref(got), _p(ws), ws.numel(), _stream())
+    if stats is not None and got.value > 0:
+        y._mvd_tile_stats16 = (stats, int(got.value))
+
+
 class Conv3dFn(Function):
     """Conv3d(k in {1,3}, pad=(k-1)/2, stride in {1,2}) over the channel concat of x1 and (optional) x2.
     Replaces nn.Conv3d of ConvDropoutNormReLU and torch.cat((x, skip), 1) (UNetDecoder.py:107)."""
@@ -439,8 +462,7 @@ class Conv3dFn(Function):
             ev0.record()
         if bf:
             wf, wb = _packed_bf16(weight, False)
-            call("mvd_conv3d_fwd_bf16", _p(x1), C1, _p(x2), C2, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3(ks), i3(stride),
-                 _p(ws), ws.numel(), _stream())
+            conv3d_fwd_bf16(x1, C1, x2, C2, wf, bias, y, N, D, H, W, K, ks, stride, ws)
         else:
             # fp32 3x3x3 stride-1 layers with enough tiles run the Winograd kernels (4/9 of the MFMA work); the packed
             # weights come from the per-weight cache (re-packed once per optimizer step, see repack_all)
@@ -555,8 +577,7 @@ class NarrowInputConv3dBf16Fn(Function):
         wf, _wb = _padded_pack_bf16(weight, cp)
         y = empty_cl3d((N, K, D, H, W), x.device, BF16)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, K), x.device)
-        call("mvd_conv3d_fwd_bf16", _p(xp), cp, None, 0, _p(wf), _p(bias), _p(y), N, D, H, W, K, i3((3, 3, 3)), i3((1, 1, 1)),
-             _p(ws), ws.numel(), _stream())
+        conv3d_fwd_bf16(xp, cp, None, 0, wf, bias, y, N, D, H, W, K, (3, 3, 3), (1, 1, 1), ws)
         ctx.save_for_backward(xp)
         ctx.params = (weight, bias)
         ctx.geom = (N, C, D, H, W, K)
@@ -676,7 +697,15 @@ class InstanceNormLeakyReLUFn(Function):
         ws = _Workspace.get(nb, x.device)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         pre = getattr(x, '_mvd_tile_stats', None)
-        if yb:
+        pre16 = getattr(x, '_mvd_tile_stats16', None) if xb else None
+        if pre16 is not None and pre16[0].shape[0] == N and pre16[0].shape[2] == C and C % 4 == 0:
+            # the bf16 conv's epilogue delivered the statistics: one finalize launch, then the apply pass in the
+            # scale / shift form (the arithmetic of the fused loader prologue, mvd_conv3d_fwd_bf16_fused)
+            scale, shift = torch.empty_like(mean), torch.empty_like(mean)
+            call("mvd_instnorm_finalize_tiles", _p(pre16[0]), pre16[1], _p(g), _p(b), _p(mean), _p(rstd), _p(scale),
+                 _p(shift), N, V, C, float(eps), _stream())
+            call("mvd_instnorm_lrelu_apply_bf16", _p(x), _p(scale), _p(shift), _p(y), N, V, C, float(slope), _stream())
+        elif yb:
             call("mvd_instnorm_lrelu_fwd_bf16", _p(x), int(xb), _p(g), _p(b), _p(y), _p(mean), _p(rstd), N, V, C,
                  float(eps), float(slope), _p(ws), ws.numel(), _stream())
         elif pre is not None and pre[0].shape[0] == N and pre[0].shape[2] == C:
@@ -719,6 +748,108 @@ class InstanceNormLeakyReLUFn(Function):
             db = None
             _grad_done(beta)
         return dx, dg, db, None, None, None
+
+
+class NormActConv3dFn(Function):
+    """The fused block boundary of the north_star (get_network_from_plans.py:41-44, bf16 mixed precision): InstanceNorm3d(affine)
+    + LeakyReLU of block k folded into the LOADER of block k+1's Conv3d 3x3x3 (mvd_conv3d_fwd_bf16_fused: z-marching
+    kernel, 32 -> 32 channels).  Input `y0` is the RAW bf16 output of block k's conv carrying the statistics its epilogue
+    emitted (`_mvd_tile_stats16`); the activated tensor a0 = lrelu(IN(y0)) is never written in the forward pass.
+    Backward: dgrad -> d a0; the InstanceNorm backward kernels on (y0, d a0) -> d y0, d gamma, d beta; the weight gradient
+    needs a0 itself, which is re-materialised by one apply pass (so under autograd the fusion moves that pass from the
+    forward to the backward step: it pays in inference, and saves the activation's memory in training)."""
+
+    @staticmethod
+    def forward(ctx, y0, gamma, beta, eps, slope, weight, bias):
+        _require_cuda(y0, gamma, beta, weight, bias)
+        pre = getattr(y0, '_mvd_tile_stats16', None)
+        if not (_is_bf16(y0) and _is_cl3d(y0)):
+            raise RuntimeError("NormActConv3dFn: needs the raw bf16 NDHWC conv output")
+        N, C, D, H, W = y0.shape
+        K = weight.shape[0]
+        V = D * H * W
+        if tuple(weight.shape[1:]) != (C, 3, 3, 3):
+            raise RuntimeError("NormActConv3dFn: 3x3x3 conv over the normalised tensor's channels")
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        mean = torch.empty((N, C), dtype=torch.float32, device=y0.device)
+        rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+        if pre is not None and pre[0].shape[0] == N and pre[0].shape[2] == C:
+            call("mvd_instnorm_finalize_tiles", _p(pre[0]), pre[1], _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N,
+                 V, C, float(eps), _stream())
+        else:   # the producing conv ran on a kernel without the statistics epilogue: one pass over y0
+            ws = _Workspace.get(query("mvd_instnorm_workspace_bytes", N, V, C), y0.device)
+            call("mvd_instnorm_stats_bf16", _p(y0), 1, _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N, V, C,
+                 float(eps), _p(ws), ws.numel(), _stream())
+        wf, wb = _packed_bf16(weight, False)
+        y1 = empty_cl3d((N, K, D, H, W), y0.device, BF16)
+        ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, V, K), y0.device)
+        conv3d_fwd_bf16(y0, C, None, 0, wf, bias, y1, N, D, H, W, K, (3, 3, 3), (1, 1, 1), ws, scale, shift, slope)
+        ctx.save_for_backward(y0, g, b, mean, rstd, scale, shift, wb)
+        ctx.params = (gamma, beta, weight, bias)
+        ctx.slope = float(slope)
+        ctx.pack16_gen = _pack16_guard(weight)
+        return y1
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy1):
+        y0, g, b, mean, rstd, scale, shift, wb = ctx.saved_tensors
+        _check_pack16_generation(ctx.pack16_gen, "norm+act+conv3d backward")
+        gamma, beta, weight, bias = ctx.params
+        N, C, D, H, W = y0.shape
+        K = weight.shape[0]
+        V = D * H * W
+        dev = y0.device
+        dy1 = to_ndhwc(dy1)
+        ks, st = i3((3, 3, 3)), i3((1, 1, 1))
+        dy0 = dg = db_ = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            da0 = empty_cl3d((N, C, D, H, W), dev, BF16)
+            ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, V, C), dev)
+            call("mvd_conv3d_dgrad_bf16", _p(dy1), _p(wb), _p(da0), C, None, 0, N, D, H, W, K, ks, st, _p(ws), ws.numel(),
+                 _stream())
+            dy0 = empty_cl3d(y0.shape, dev, BF16)
+            sink_g, sink_b = _take_grad(gamma), _take_grad(beta)
+            dg = sink_g if sink_g is not None else torch.empty((C,), dtype=torch.float32, device=dev)
+            db_ = sink_b if sink_b is not None else torch.empty((C,), dtype=torch.float32, device=dev)
+            ws = _Workspace.get(query("mvd_instnorm_workspace_bytes", N, V, C), dev)
+            call("mvd_instnorm_lrelu_bwd_bf16", _p(y0), 1, _p(da0), _p(g), _p(b), _p(mean), _p(rstd), _p(dy0), _p(dg), _p(db_),
+                 N, V, C, ctx.slope, _p(ws), ws.numel(), _stream())
+            if sink_g is not None:
+                dg = None
+                _grad_done(gamma)
+            if sink_b is not None:
+                db_ = None
+                _grad_done(beta)
+        if ctx.needs_input_grad[5]:
+            a0 = empty_cl3d(y0.shape, dev, BF16)  # the activated tensor, only now (and only for the weight gradient)
+            call("mvd_instnorm_lrelu_apply_bf16", _p(y0), _p(scale), _p(shift), _p(a0), N, V, C, ctx.slope, _stream())
+            has_bias = bias is not None
+            sink_w, sink_b2 = _take_grad(weight), (_take_grad(bias) if has_bias else None)
+            dw = sink_w if sink_w is not None else torch.empty((K, C, 3, 3, 3), dtype=torch.float32, device=dev)
+            db = (sink_b2 if sink_b2 is not None else torch.empty((K,), dtype=torch.float32, device=dev)) if has_bias else None
+            ws = _Workspace.get(query("mvd_conv3d_wgrad_workspace_bytes", C, K, 27, N, D, H, W), dev)
+            call("mvd_conv3d_wgrad_bf16", _p(a0), C, None, 0, _p(dy1), _p(dw), _p(db), N, D, H, W, K, ks, st, _p(ws),
+                 ws.numel(), _stream())
+            if sink_w is not None:
+                dw = None
+                _grad_done(weight)
+            if sink_b2 is not None:
+                db = None
+                _grad_done(bias)
+        return dy0, dg, db_, None, None, dw, db
+
+
+def fused_norm_conv_ok(y0, weight, stride):
+    """True when `y0` (raw bf16 conv output) can feed the next 3x3x3 conv through the fused loader
+    prologue (mvd_conv3d_fwd_bf16_fused: the z-marching kernel takes the shape)."""
+    if not (_is_bf16(y0) and y0.dim() == 5 and _is_cl3d(y0)):
+        return False
+    N, C, D, H, W = y0.shape
+    K = weight.shape[0]
+    if tuple(weight.shape[1:]) != (C, 3, 3, 3) or tuple(stride) != (1, 1, 1):
+        return False
+    return C % 4 == 0 and query("mvd_conv3d_fwd_bf16_prologue_ok", N, D, H, W, C, 0, K, i3((3, 3, 3)), i3((1, 1, 1))) > 0
 
 
 # ======================================================================================================== seg head

@@ -156,3 +156,90 @@ def test_cfg3_dual_branch_fp32_real_widths_step_vs_oracle():
     for n, p in tr.network.named_parameters():
         e = float((p.detach().cpu() - ref[n].detach()).abs().max())
         assert e <= 2e-5, f"param after step: {n}: {e:.3e}"
+
+
+# ====================================================================================== full-size configs[2] / configs[3]
+def _full_size_dual(seed1, seed2, bseed):
+    from oracle import loss_oracle as LO, step_oracle as SO, unet_oracle as UO
+    cfg = UO.CONFIGS["cfg2"]   # configs[2..3] use the configs[1] network and patch: 6 stages, 4 x 128^3
+    ora = UO.DualBranchNet(UO.build_plainconv_unet(4, 5, cfg["n_stages"], cfg["strides"], seed=seed1),
+                           UO.build_plainconv_unet(4, 5, cfg["n_stages"], cfg["strides"], seed=seed2))
+    batch = SO.synthetic_batch(1, 4, cfg["patch"], cfg["strides"], num_classes=5, seed=bseed)
+    return ora, LO.build_loss(len(batch["target"])), batch, cfg
+
+
+def _full_size_trainer(cfg, ora, precision, use_topo):
+    from multimodal_mvd_seg_amd import trainer
+    plans = trainer.make_plans(cfg["patch"], cfg["strides"], batch_size=1)
+    ds = {"channel_names": {str(i): str(i) for i in range(4)},
+          "labels": {"background": 0, "a": 1, "b": 2, "c": 3, "d": 4}}
+    tr = trainer.ContrastiveTrainerMI355(plans, "3d_fullres", 0, ds, device=DEV)
+    tr.precision = precision
+    tr.use_hip_graph = False
+    tr.initialize()
+    tr.network.load_state_dict(ora.state_dict())
+    tr.skel_iter, tr.use_topo = 3, use_topo
+    tr.on_train_epoch_start()
+    return tr
+
+
+def test_cfg3_full_size_dual_branch_fp32_step_vs_oracle():
+    """BASELINE configs[2] at FULL size: two 6-stage 31.2 M-parameter branches on the 4 x 128^3 patch,
+    batch 1, fp32: loss = DC+CE(out1) + DC+CE(out2) + 0.5 * (KL(vessel logits) + feature KL) (MVDTrainer.py:879-925) and
+    every parameter of both branches after clip + SGD against oracle/step_oracle.mvd_train_step on the host: loss 2e-5,
+    gradient norm 1e-3, parameters 2e-5."""
+    from oracle import step_oracle as SO
+    ora, loss_fn, batch, cfg = _full_size_dual(4, 5, 78)
+    tr = _full_size_trainer(cfg, ora, "fp32", False)
+    opt = SO.make_optimizer(ora.parameters())
+    l_ref, _, gn_ref = SO.mvd_train_step(ora, loss_fn, opt, batch, use_topo=False, feat_kl=True)
+    res = tr.train_step({"data": batch["data"].to(DEV), "target": [t.to(DEV) for t in batch["target"]]})
+    assert abs(float(res["loss"]) - float(l_ref)) <= 2e-5 * max(1.0, abs(float(l_ref))), (float(res["loss"]), float(l_ref))
+    assert abs(float(tr.optimizer.grad_norm()) - gn_ref) <= 1e-3 * gn_ref
+    ref = dict(ora.named_parameters())
+    worst = 0.0
+    for n, p in tr.network.named_parameters():
+        e = float((p.detach().cpu() - ref[n].detach()).abs().max())
+        worst = max(worst, e)
+        assert e <= 2e-5, f"param after step: {n}: {e:.3e}"
+    print(f"[cfg3 full size] loss hip {float(res['loss']):.7f} oracle {float(l_ref):.7f}; worst param err {worst:.2e}")
+
+
+def test_cfg4_full_size_dual_branch_bf16_topology_step_vs_oracle():
+    """BASELINE configs[3] at FULL size (one GPU of the eight): cfg 3 + soft-clDice on the vessel channel + the integer
+    component count, bf16 mixed precision, 4 x 128^3, batch 1, against the fp32 host oracle (an fp64 evaluation of two
+    31 M-parameter branches at 128^3 does not finish in test time; the 32^3 test above holds the bf16 engine to the
+    fp64 / torch-autocast bar).
+    * integer work, bit-exact: the soft skeleton of the 128^3 vessel probability map (LO.soft_skel on the host, the same
+      min/max/relu arithmetic) and the connected-component counts (oracle/cc_oracle.c) of the masks the step counted;
+    * floating point, bf16 bar (8-bit mantissa, ~60 layers): |loss - fp32 oracle loss| <= 1 % and the global gradient norm
+      within 5 % -- the fp32 oracle is the reference's -device cpu path, which has no autocast (nnUNetTrainer.py:906)."""
+    from multimodal_mvd_seg_amd import losses, ops
+    from oracle import cc_oracle, loss_oracle as LO, step_oracle as SO
+    ora, loss_fn, batch, cfg = _full_size_dual(2, 3, 77)
+    tr = _full_size_trainer(cfg, ora, "bf16", True)
+    gbatch = {"data": batch["data"].to(DEV), "target": [t.to(DEV) for t in batch["target"]]}
+    # soft skeleton of the vessel probability the HIP network produces, on the device and on the host: bit-exact
+    with torch.no_grad():
+        o1 = tr.network(gbatch["data"])[0][0]
+        prob = ops.SoftmaxSelectFn.apply(o1, tr.vessel_channel)
+        sk = losses.soft_skel(prob, 3)
+    assert torch.equal(sk.cpu(), LO.soft_skel(prob.cpu(), 3)), "soft skeleton of the 128^3 vessel map"
+    del o1, sk
+    l_ref, _ = SO.mvd_loss(ora, loss_fn, batch, use_topo=True, skel_iter=3, feat_kl=True)
+    l_ref.backward()
+    gn_ref = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ora.parameters())))
+    res = tr.train_step(gbatch)
+    l = float(res["loss"])
+    assert abs(l - float(l_ref)) <= 1e-2 * abs(float(l_ref)), (l, float(l_ref))
+    gn = float(tr.optimizer.grad_norm())
+    assert abs(gn - gn_ref) <= 5e-2 * gn_ref, (gn, gn_ref)
+    # the integer step of the same train step: counts of the masks it saw
+    topo = tr.last_topology
+    tmask = (batch["target"][0][0, 0] == tr.vessel_channel).numpy()
+    assert int(topo["cc_true"][0]) == cc_oracle.cc_label(tmask, 26)[1]
+    pmask = ops.threshold_mask(prob[0, 0].contiguous(), 0.5, ge=True).cpu().numpy().astype(bool)
+    assert int(topo["cc_pred"][0]) == cc_oracle.cc_label(pmask, 26)[1]
+    assert int(topo["betti0_error"][0]) == abs(int(topo["cc_pred"][0]) - int(topo["cc_true"][0]))
+    print(f"[cfg4 full size] loss hip {l:.6f} fp32 oracle {float(l_ref):.6f}; grad norm hip {gn:.4f} oracle {gn_ref:.4f}; "
+          f"components pred {int(topo['cc_pred'][0])} true {int(topo['cc_true'][0])}")
