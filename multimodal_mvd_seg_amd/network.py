@@ -20,6 +20,8 @@ from . import ops
 
 # InstanceNorm-apply + LeakyReLU in the consumer conv's loader (bf16, z-marching kernel): on in inference; under autograd
 # only on request (the weight gradient needs the activated tensor and re-materialises it)
+# gradient contributions of a tensor with two consumers summed inside the second consumer's kernel (ops._GradShare)
+SHARE_GRADS = [os.environ.get("MVD_SHARE_GRADS", "1") != "0"]
 FUSE_PROLOGUE = [os.environ.get("MVD_FUSE_PROLOGUE", "1") != "0"]
 FUSE_PROLOGUE_TRAIN = [os.environ.get("MVD_FUSE_PROLOGUE_TRAIN", "0") == "1"]
 
@@ -271,6 +273,8 @@ class UNetDecoder(nn.Module):
         for level, (up, refine, head) in enumerate(zip(self.transpconvs, self.stages, self.seg_layers)):
             # the concatenation of (up-sampled, skip) is never materialised: the first conv reads both pointers
             feat = refine(up(feat), skips[-(level + 2)])
+            if self.deep_supervision and level != last and SHARE_GRADS[0]:
+                ops.share_grad(feat)   # two consumers (this level's seg head, the next level's up-sampling): one gradient buffer
             if self.deep_supervision:
                 logits.append(head(feat))
             elif level == last:

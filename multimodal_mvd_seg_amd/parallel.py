@@ -77,7 +77,7 @@ class BucketedGradReducer:
     instead of dropping the late gradient.  `optimizer` (FusedSGDNesterov) receives grad_scale = 1/world so that the
     mean is taken inside the optimizer kernel."""
 
-    def __init__(self, flat_params, bucket_bytes=25 * 1024 * 1024, process_group=None, optimizer=None):
+    def __init__(self, flat_params, bucket_bytes=25 * 1024 * 1024, process_group=None, optimizer=None, always_hook=False):
         self.fp = flat_params
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -99,14 +99,15 @@ class BucketedGradReducer:
             for i in idx:
                 self.bucket_of[i] = b
         self._hooks = []
-        if self.world > 1:
+        self.always_hook = always_hook   # measurement aid (tools/ddp_overlap_probe.py): hooks and bucket logic at world 1
+        if self.world > 1 or always_hook:
             for i, p in enumerate(self.fp.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
             self.uses_listener = not _hook_fires_for_undefined_grad()
             listeners = getattr(self.fp, 'listeners', None)
             if self.uses_listener and listeners is not None:
                 listeners.append(self._on_ready)
-            if optimizer is not None:
+            if optimizer is not None and self.world > 1:
                 optimizer.grad_scale = 1.0 / self.world
         self.reset()
 
@@ -138,6 +139,8 @@ class BucketedGradReducer:
         s, e, _ = self.buckets[b]
         self._launched[b] = True
         buf = self.fp.grad[s:e]
+        if self.world <= 1:   # (always_hook at world 1: the bucket bookkeeping without a collective)
+            return
         # async_op=True: the collective runs on the process group's own stream, ordered after the kernels already
         # enqueued on the current stream (the wgrad that produced this bucket); backward continues meanwhile.
         work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -148,6 +151,8 @@ class BucketedGradReducer:
         the collectives and takes the mean over ranks (DDP semantics) -- inside the optimizer kernel when an optimizer
         was given, else with one scaling pass."""
         if self.world <= 1:
+            if self.always_hook:
+                self.reset()
             return
         for b in range(len(self.buckets)):
             if not self._launched[b]:
