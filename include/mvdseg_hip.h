@@ -160,6 +160,17 @@ int mvd_convT3d_wgrad_bf16(const uint16_t *x, const uint16_t *dy, float *dw, flo
  *     the consumers that have none.  The backward pass is mvd_instnorm_lrelu_bwd_bf16 on (x, mean, rstd). */
 int mvd_conv3d_fwd_bf16_stats_tiles(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
                                     const int stride[3]);
+/* Gradient of a tensor with TWO consumers (a skip connection: the next encoder stage's strided conv and the decoder conv
+ * that reads it as its second pointer, UNetDecoder.py:106-108): the consumer whose backward runs second adds its input
+ * gradient into the buffer the first one wrote, inside its own kernel, instead of autograd's separate elementwise add.
+ *   mvd_conv3d_dgrad_acc_ok: 1 when an accumulating kernel exists for the conv (3x3x3, stride 2, 32-multiple channels).
+ *   mvd_conv3d_dgrad_acc / _bf16_acc: dx1 += input gradient (fp32: a + b as torch's add; bf16: fp32 add of the two bf16
+ *   values, one rounding, as torch's bf16 add). */
+int mvd_conv3d_dgrad_acc_ok(int is_bf16, int N, int D, int H, int W, int C1, int K, const int ksize[3], const int stride[3]);
+int mvd_conv3d_dgrad_acc(const float *dy, const float *wb, float *dx1, int C1, int N, int D, int H, int W, int K,
+                         const int ksize[3], const int stride[3], void *stream);
+int mvd_conv3d_dgrad_bf16_acc(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, int N, int D, int H, int W, int K,
+                              const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream);
 /* which z-marching kernel serves the 3x3x3 stride-1 convs with 32 produce channels at the patch resolution: 1 (default,
  * MVD_FWD16Y) = k_fwd16y (16x16x32 tiles; 32 or 64 reduce channels; statistics epilogue and loader prologue), 0 =
  * k_fwd16z (32x32x16 tiles, 32 reduce channels, loader prologue only).  A/B and cross-check switch. */

@@ -53,6 +53,9 @@ SIGNATURES = {
                                                 _P, c_size_t, _P]),
     "mvd_conv3d_fwd_bf16_stats_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
     "mvd_set_bf16_zmarch_kernel": (c_int, [c_int]),
+    "mvd_conv3d_dgrad_acc_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
+    "mvd_conv3d_dgrad_acc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P]),
+    "mvd_conv3d_dgrad_bf16_acc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P, c_size_t, _P]),
     "mvd_conv3d_fwd_bf16_prologue_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
     "mvd_instnorm_stats_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, _P, c_size_t, _P]),
     "mvd_conv3d_fwd_bf16_fused": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,

@@ -776,8 +776,9 @@ int mvd_conv3d_fwd_bf16_fused(const uint16_t *x1, int C1, const uint16_t *x2, in
     return run_fwd16(g, x1, x2, wf, bias, y, nullptr, ws, ws_bytes, as_stream(stream), &f);
 }
 
-int mvd_conv3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, uint16_t *dx2, int C2, int N, int D, int H, int W,
-                     int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+static int dgrad_bf16_impl(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, uint16_t *dx2, int C2, int N, int D, int H,
+                           int W, int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream,
+                           int acc) {
     MVD_REQUIRE(dy && wb && dx1 && C1 > 0 && C2 >= 0 && (C2 == 0 || dx2), "conv3d_dgrad_bf16: null pointer / bad channels");
     MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_dgrad_bf16: bad shape");
     if (check_ks(ksize, stride, "conv3d_dgrad_bf16")) return 2;
@@ -828,11 +829,52 @@ int mvd_conv3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1,
                         }
                 g.ntaps = nt;
                 g.T = ksize[0] * ksize[1] * ksize[2];
+                g.acc = (int8_t)acc;
                 if (nt == 0) continue;
                 int r = run_fwd16(g, dy, nullptr, wb, nullptr, dx1, dx2, ws, ws_bytes, as_stream(stream));
                 if (r) return r;
             }
     return 0;
+}
+
+int mvd_conv3d_dgrad_bf16(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, uint16_t *dx2, int C2, int N, int D, int H, int W,
+                     int K, const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    return dgrad_bf16_impl(dy, wb, dx1, C1, dx2, C2, N, D, H, W, K, ksize, stride, ws, ws_bytes, stream, 0);
+}
+
+static bool strided3(const int ksize[3], const int stride[3]) {
+    return ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3 && (stride[0] == 2 || stride[1] == 2 || stride[2] == 2);
+}
+
+int mvd_conv3d_dgrad_acc_ok(int is_bf16, int N, int D, int H, int W, int C1, int K, const int ksize[3], const int stride[3]) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C1 <= 0 || K <= 0 || check_ks(ksize, stride, "conv3d_dgrad_acc_ok")) return 0;
+    if (C1 % 32 || K % 32 || g_engine_mode != 0) return 0;
+    if (is_bf16) return strided3(ksize, stride) ? 1 : 0;   // every parity class runs on the generic bf16 kernel
+    if (!(ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3 && stride[0] == 2 && stride[1] == 2 && stride[2] == 2)) return 0;
+    const long items = (long)N * out_dim(D, 3, 2) * out_dim(H, 3, 2) * out_dim(W, 3, 2);
+    static int dg2 = -1;
+    if (dg2 < 0) dg2 = getenv("MVD_DGRAD2") ? atoi(getenv("MVD_DGRAD2")) : 1;
+    return (dg2 && (items >= 4096 || g_wino_min_items <= 1) && (long)out_dim(D, 3, 2) * out_dim(H, 3, 2) * out_dim(W, 3, 2) * K * 4 < (1L << 31)) ? 1 : 0;
+}
+
+int mvd_conv3d_dgrad_bf16_acc(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1, int C1, int N, int D, int H, int W, int K,
+                              const int ksize[3], const int stride[3], void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(mvd_conv3d_dgrad_acc_ok(1, N, D, H, W, C1, K, ksize, stride), "conv3d_dgrad_bf16_acc: no accumulating kernel for this "
+                "shape (ask mvd_conv3d_dgrad_acc_ok first)");
+    return dgrad_bf16_impl(dy, wb, dx1, C1, nullptr, 0, N, D, H, W, K, ksize, stride, ws, ws_bytes, stream, 1);
+}
+
+int mvd_conv3d_dgrad_acc(const float *dy, const float *wb, float *dx1, int C1, int N, int D, int H, int W, int K,
+                         const int ksize[3], const int stride[3], void *stream) {
+    MVD_REQUIRE(dy && wb && dx1, "conv3d_dgrad_acc: null pointer");
+    MVD_REQUIRE(mvd_conv3d_dgrad_acc_ok(0, N, D, H, W, C1, K, ksize, stride), "conv3d_dgrad_acc: no accumulating kernel for this shape "
+                "(ask mvd_conv3d_dgrad_acc_ok first)");
+    int r = dgrad32s(N, D, H, W, C1, K, out_dim(D, 3, 2), out_dim(H, 3, 2), out_dim(W, 3, 2), dy, wb, dx1, as_stream(stream), 1);
+    if (r < 0) {
+        set_error("conv3d_dgrad_acc: the fused stride-2 kernel refused the shape");
+        return 3;
+    }
+    return r;
 }
 
 int mvd_convT3d_fwd_bf16(const uint16_t *x, const uint16_t *wf, const float *bias, uint16_t *y, int N, int D, int H, int W, int C, int K,

@@ -30,6 +30,18 @@ __device__ inline uint4 pair_store_image(uint2 a /* group k */, uint2 b /* group
     auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
+// img + old, element-wise on 8 packed bf16 (fp32 add, one rounding): the accumulate form of the epilogue (FwdGeom::acc)
+__device__ inline uint4 add_bf16x8(uint4 a, uint4 b) {
+    const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    unsigned r[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float lo = __uint_as_float(av[e] << 16) + __uint_as_float(bv[e] << 16);
+        const float hi = __uint_as_float(av[e] & 0xffff0000u) + __uint_as_float(bv[e] & 0xffff0000u);
+        r[e] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
 __device__ inline uint2 pack_bf16x4(float a, float b, float c, float d) {
     uint2 q;
     q.x = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
@@ -359,9 +371,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
                     const uint4 img = pair_store_image(pk[0], pk[1]);
                     const int k = kb * KT + q * 32 + 16 * kp + 8 * h;  // first of this lane's 8 consecutive channels
                     if (inside && !(MVD_F16_DBG & 32)) {
-                        if (k < g.K1)
-                            *reinterpret_cast<uint4 *>(y1 + ov * g.K1 + k) = img;
-                        else
+                        if (k < g.K1) {
+                            uint4 *dst = reinterpret_cast<uint4 *>(y1 + ov * g.K1 + k);
+                            *dst = g.acc ? add_bf16x8(img, *dst) : img;   // (block-uniform)
+                        } else
                             *reinterpret_cast<uint4 *>(y2 + ov * g.K2 + (k - g.K1)) = img;
                     }
                 }
@@ -398,7 +411,7 @@ __global__ void k_split_reduce16(const FwdGeom g, const float *__restrict__ part
         const size_t ov = (((size_t)n * g.Dy + (od * g.so[0] + g.oo[0])) * g.Hy + (oh * g.so[1] + g.oo[1])) * g.Wy +
                           (ow * g.so[2] + g.oo[2]);
         if (k < g.K1)
-            y1[ov * g.K1 + k] = f2bf(s);
+            y1[ov * g.K1 + k] = f2bf(g.acc ? s + __uint_as_float((unsigned)y1[ov * g.K1 + k] << 16) : s);
         else
             y2[ov * g.K2 + (k - g.K1)] = f2bf(s);
     }
@@ -1422,7 +1435,7 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
     // 32 reduce channels; 32 produce channels, or 32 + 32 into two tensors (the input gradient of a conv that read two
     // concatenated 32-channel tensors: two independent 32 -> 32 problems on the same dy; k_fwd16z only)
     const bool two_out = g.K1 == 32 && g.K2 == 32 && y2 != nullptr;
-    if (g.C1 != 32 || g.C2 != 0 || g.K1 != 32 || (g.K2 != 0 && !two_out) || g.ntaps != 27 || g.T != 27) return -1;
+    if (g.C1 != 32 || g.C2 != 0 || g.K1 != 32 || (g.K2 != 0 && !two_out) || g.ntaps != 27 || g.T != 27 || g.acc) return -1;
     for (int a = 0; a < 3; a++)
         if (g.sa[a] != 1 || g.so[a] != 1 || g.oo[a] != 0) return -1;
     if (g.Dy != g.Do || g.Hy != g.Ho || g.Wy != g.Wo) return -1;

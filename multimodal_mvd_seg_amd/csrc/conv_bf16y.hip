@@ -38,8 +38,13 @@ typedef float f32x2y __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2y __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x4y lds_u4y;
 
-constexpr int Y_ROWP = 40, Y_SROW = 34, Y_ROWS = 10, Y_PARTS = Y_ROWS * Y_SROW * 4, Y_XR = 6;
-constexpr int Y_CHUNK = Y_ROWS * Y_ROWP * 64;  // bytes of one 32-channel plane image
+constexpr int Y_ROWP = 40, Y_SROW = 34;
+// KQ = 16-channel output groups of the workgroup's four waves: 2 (32 produce channels: 2 row groups x 2 halves, an 8 x 32
+// column) or 4 (64 produce channels: ONE row group x 4 quarters, a 4 x 32 column)
+constexpr int y_rows(int KQ) { return 4 * (4 / KQ) + 2; }                       // halo rows of a plane image
+constexpr int y_parts(int KQ) { return y_rows(KQ) * Y_SROW * 4; }               // 16-byte parts of a chunk's plane
+constexpr int y_xr(int KQ) { return (y_parts(KQ) + 255) / 256; }                // staging rounds per chunk
+constexpr int y_chunk(int KQ) { return y_rows(KQ) * Y_ROWP * 64; }              // bytes of one 32-channel plane image
 
 struct Fwd16YTile {
     int nty, ntx, nzc, zc, nitems;
@@ -71,7 +76,7 @@ __device__ __forceinline__ void y_slots(F &&f) {
     y_slots_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <int NCH, int FUSE>
+template <int NCH, int FUSE, int KQ = 2>
 __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16YTile tg, const unsigned short *__restrict__ a1,
                                                    const unsigned short *__restrict__ a2, const unsigned short *__restrict__ w,
                                                    const float *__restrict__ bias, unsigned short *__restrict__ y1,
@@ -79,6 +84,8 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
                                                    const float *__restrict__ in_shift, const float slope) {
     constexpr bool ST = (FUSE & 1) != 0, PRO = (FUSE & 2) != 0;
     static_assert(!(PRO && NCH != 1), "the loader prologue normalises ONE 32-channel producer");
+    constexpr int RG = 4 / KQ;                                    // row groups of four output rows
+    constexpr int Y_PARTS = y_parts(KQ), Y_XR = y_xr(KQ), Y_CHUNK = y_chunk(KQ), OB = 32 * KQ;  // OB: bytes per output voxel
     constexpr int IMG = NCH * Y_CHUNK;   // bytes of a plane image (all chunks)
     constexpr int NS = 36 * NCH;         // fragment slots per plane: (chunk, input row r, x half, dx)
     constexpr int NSET = NCH == 1 ? 2 : 1;  // planes in flight in registers (NCH = 2: a plane takes twice as long)
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
     const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave >> 1, kh = wave & 1;      // row group (output rows 4 rg .. 4 rg + 3), half of the output channels
+    const int rg = KQ == 2 ? wave >> 1 : 0, kh = KQ == 2 ? wave & 1 : wave;  // row group (output rows 4 rg .. + 3), 16-channel group
     const int n16 = lane & 15, kq = lane >> 4;
     // XCD-aware item order: each XCD walks a contiguous range of (n, chunk, ty, tx) -- neighbours share halo rows in its L2
     const int per_xcd = (tg.nitems + 7) >> 3;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
     const int ty = (int)(r_ % (unsigned)tg.nty); r_ /= (unsigned)tg.nty;
     const int zchunk = (int)(r_ % (unsigned)tg.nzc);
     const int n_ = (int)(r_ / (unsigned)tg.nzc);
-    const int y0 = ty * 8, x0 = tx * 32, zb = zchunk * tg.zc;
+    const int y0 = ty * (4 * RG), x0 = tx * 32, zb = zchunk * tg.zc;
     const int ze = min(zb + tg.zc, g.Do);
 
     // weights: A operand of the swapped product D^T = W^T X^T -- lane (m = n16, kq) holds reduce channels 8 kq .. 8 kq + 7
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const int oh = y0 + 4 * rg + m, ow = x0 + (kq & 1) * 16 + n16;
-        voff[m] = (oh < g.Ho && ow < g.Wo) ? (unsigned)((oh * g.Wy + ow) * 64 + kh * 32 + (kq >> 1) * 16) : 0xfffffff0u;
+        voff[m] = (oh < g.Ho && ow < g.Wo) ? (unsigned)((oh * g.Wy + ow) * OB + kh * 32 + (kq >> 1) * 16) : 0xfffffff0u;
     }
     asm volatile("" : "+v"(voff[0]), "+v"(voff[1]), "+v"(voff[2]), "+v"(voff[3]));
     float bq[4];  // bias of this lane's 4 channels (D rows 4 kq + e of the wave's 16)
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
 #pragma unroll
     for (int e = 0; e < (ST ? 4 : 1); e++) ssum[e] = ssq[e] = 0.f;
 
-    const size_t oplane = (size_t)g.Hy * g.Wy * 64;
+    const size_t oplane = (size_t)g.Hy * g.Wy * OB;
     char *ybase = reinterpret_cast<char *>(y1) + (size_t)n_ * g.Dy * oplane;
     const size_t iplane = (size_t)g.Hi * g.Wi * tg.vstride;
     const char *abase[NCH];
@@ -300,13 +307,13 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
             // r = 1 slots, the drained set (conversion + lane-row exchange + store + bias reset, one tile pair per slot) in
             // the r = 2 slots, the loads of plane j+3 into the freed registers in the r = 3 slots.
             if (NCH == 1) {
-                if (s >= 6 && s < 12) stage_write((R + 1) & 1, 0, IN_ * IMG, s - 6, lvn);
+                if (s >= 6 && s < 6 + Y_XR) stage_write((R + 1) & 1, 0, IN_ * IMG, s - 6, lvn);
                 if (s >= 12 && s < 16) epilogue_pair(s - 12);
-                if (s >= 18 && s < 24) stage_load((R + 1) & 1, 0, s - 18);
+                if (s >= 18 && s < 18 + Y_XR) stage_load((R + 1) & 1, 0, s - 18);
             } else {  // 72 slots: writes 6..17, drained set 18..21, loads of plane j+2 in the second chunk's long slots
-                if (s >= 6 && s < 18) stage_write(0, (s - 6) / 6, IN_ * IMG, (s - 6) % 6, lvn);
+                if (s >= 6 && s < 6 + 2 * Y_XR) stage_write(0, (s - 6) / Y_XR, IN_ * IMG, (s - 6) % Y_XR, lvn);
                 if (s >= 18 && s < 22) epilogue_pair(s - 18);
-                if (s >= 42 && s < 54) stage_load(0, (s - 42) / 6, (s - 42) % 6);
+                if (s >= 42 && s < 42 + 2 * Y_XR) stage_load(0, (s - 42) / Y_XR, (s - 42) % Y_XR);
             }
             // plane j+1 complete in LDS (this wave's writes retired in order before the fragment reads it has consumed since),
             // and no read of this plane's image is issued behind the barrier (the read above was its last): the next plane
@@ -356,9 +363,11 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
             }
         }
         __syncthreads();
-        if (tid < 64) {
+        if (tid < 32 * KQ) {   // [16 KQ channels][2]
             const int c = tid >> 1, which = tid & 1, khc = c >> 4, cl = c & 15;
-            const float a = wtot[((0 * 2 + khc) * 16 + cl) * 2 + which] + wtot[((1 * 2 + khc) * 16 + cl) * 2 + which];
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < RG; r++) a += wtot[((r * KQ + khc) * 16 + cl) * 2 + which];   // wave = rg * KQ + kh (KQ = 2) / kh
             const int tile = (zchunk * tg.nty + ty) * tg.ntx + tx;
             tile_stats[(((size_t)n_ * ((size_t)tg.nzc * tg.nty * tg.ntx) + tile) * tg.kp + tg.koff) * 2 + tid] = a;
         }
@@ -377,9 +386,12 @@ int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned sho
                   const float *bias, unsigned short *y1, unsigned short *y2, hipStream_t s, const Fwd16Fuse *fuse, int ncu,
                   int *stats_tiles_only) {
     if (!fwd16y_enabled()) return -1;
-    const bool two_out = g.K1 == 32 && g.K2 == 32 && y2 != nullptr;
+    const int KT = g.K1;                                   // produce channels per launch: 32 (KQ = 2) or 64 (KQ = 4)
+    if (KT != 32 && KT != 64) return -1;
+    const int KQ = KT / 16, rows = 4 * (4 / KQ);
+    const bool two_out = g.K2 == KT && y2 != nullptr;
     if (stats_tiles_only && g.K2 != 0) return -1;
-    if (g.K1 != 32 || (g.K2 != 0 && !two_out) || g.ntaps != 27 || g.T != 27) return -1;
+    if ((g.K2 != 0 && !two_out) || g.ntaps != 27 || g.T != 27 || g.acc) return -1;
     int nch, vstride;
     if (g.C1 == 32 && g.C2 == 0) { nch = 1; vstride = 64; }
     else if (g.C1 == 32 && g.C2 == 32) { nch = 2; vstride = 64; }
@@ -388,7 +400,7 @@ int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned sho
     for (int a = 0; a < 3; a++)
         if (g.sa[a] != 1 || g.so[a] != 1 || g.oo[a] != 0) return -1;
     if (g.Dy != g.Do || g.Hy != g.Ho || g.Wy != g.Wo || g.Di != g.Do || g.Hi != g.Ho || g.Wi != g.Wo) return -1;
-    if ((long)g.Hi * g.Wi * vstride >= (1L << 31) || (long)g.Hy * g.Wy * 64 >= (1L << 31)) return -1;
+    if ((long)g.Hi * g.Wi * vstride >= (1L << 31) || (long)g.Hy * g.Wy * 2 * KT >= (1L << 31)) return -1;
     Fwd16YTile tz;
     memset(&tz, 0, sizeof(tz));
     for (int p = 0; p < 27; p++) {
@@ -399,10 +411,10 @@ int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned sho
         if (hit < 0) return -1;
         tz.wsel[p] = g.wt[hit];
     }
-    tz.nty = (g.Ho + 7) / 8;
+    tz.nty = (g.Ho + rows - 1) / rows;
     tz.ntx = (g.Wo + 31) / 32;
     // large volumes only (>= 4 4x8x8 tiles per CU, the threshold of the other weights-resident kernels)
-    if ((long)g.N * ((g.Do + 3) / 4) * tz.nty * ((g.Wo + 7) / 8) < 4L * ncu) return -1;
+    if ((long)g.N * ((g.Do + 3) / 4) * ((g.Ho + 7) / 8) * ((g.Wo + 7) / 8) < 4L * ncu) return -1;
     const long cols = (long)g.N * tz.nty * tz.ntx;
     int best = 1;
     double best_cost = 1e30;
@@ -416,7 +428,7 @@ int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned sho
     tz.nzc = (g.Do + tz.zc - 1) / tz.zc;
     tz.nitems = (int)(cols * tz.nzc);
     tz.vstride = vstride;
-    const bool stats_ok = !two_out && g.Ho % 8 == 0 && g.Wo % 32 == 0;
+    const bool stats_ok = !two_out && g.Ho % rows == 0 && g.Wo % 32 == 0;
     if (stats_tiles_only) {
         *stats_tiles_only = stats_ok ? tz.nzc * tz.nty * tz.ntx : 0;
         return 0;
@@ -427,26 +439,28 @@ int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned sho
     if (fuse && fuse->ntiles) *fuse->ntiles = want_stats ? tz.nzc * tz.nty * tz.ntx : 0;
     typedef void (*ky_t)(const FwdGeom, const Fwd16YTile, const unsigned short *, const unsigned short *, const unsigned short *,
                          const float *, unsigned short *, float *, const float *, const float *, const float);
-    static const ky_t kern[2][4] = {{k_fwd16y<1, 0>, k_fwd16y<1, 1>, k_fwd16y<1, 2>, k_fwd16y<1, 3>},
-                                    {k_fwd16y<2, 0>, k_fwd16y<2, 1>, nullptr, nullptr}};
-    const int fz = (want_stats ? 1 : 0) | (want_pro ? 2 : 0);
-    const ky_t kfn = kern[nch - 1][fz];
-    const size_t lds = 2 * (size_t)nch * Y_CHUNK;
-    static bool configured[2][4] = {{false, false, false, false}, {false, false, false, false}};
-    if (!configured[nch - 1][fz]) {
+    static const ky_t kern[2][2][4] = {{{k_fwd16y<1, 0, 2>, k_fwd16y<1, 1, 2>, k_fwd16y<1, 2, 2>, k_fwd16y<1, 3, 2>},
+                                        {k_fwd16y<2, 0, 2>, k_fwd16y<2, 1, 2>, nullptr, nullptr}},
+                                       {{k_fwd16y<1, 0, 4>, k_fwd16y<1, 1, 4>, k_fwd16y<1, 2, 4>, k_fwd16y<1, 3, 4>},
+                                        {k_fwd16y<2, 0, 4>, k_fwd16y<2, 1, 4>, nullptr, nullptr}}};
+    const int fz = (want_stats ? 1 : 0) | (want_pro ? 2 : 0), ki = KQ == 2 ? 0 : 1;
+    const ky_t kfn = kern[ki][nch - 1][fz];
+    const size_t lds = 2 * (size_t)nch * (KQ == 2 ? y_chunk(2) : y_chunk(4));
+    static bool configured[2][2][4] = {};
+    if (!configured[ki][nch - 1][fz]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)(2 * 2 * Y_CHUNK));
+                                                 (int)(2 * 2 * y_chunk(2)));
         if (e != hipSuccess) {
             set_error("conv fwd16y: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
             return 1;
         }
-        configured[nch - 1][fz] = true;
+        configured[ki][nch - 1][fz] = true;
     }
     const int per_xcd = (tz.nitems + 7) / 8;
     tz.kp = g.K1 + g.K2;
     const unsigned short *c1 = vstride == 128 ? a1 + 32 : a2;  // second chunk: the other tensor, or channels 32.. of the one
     for (int q = 0; q < (two_out ? 2 : 1); q++) {
-        tz.koff = 32 * q;
+        tz.koff = KT * q;
         hipLaunchKernelGGL(kfn, dim3((unsigned)(per_xcd * 8)), dim3(256), lds, s, g, tz, a1, c1, w, bias, q ? y2 : y1,
                            want_stats ? fuse->tile_stats : nullptr, want_pro ? fuse->in_scale : nullptr,
                            want_pro ? fuse->in_shift : nullptr, fuse ? fuse->slope : 0.f);

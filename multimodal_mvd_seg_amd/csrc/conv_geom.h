@@ -41,6 +41,8 @@ struct FwdGeom {
     int sa[3], so[3], oo[3];
     int8_t off[27][3];
     int8_t wt[27];
+    int8_t acc;  // 1: y1 += result (the gradient of a tensor with a second consumer, ops._GradShare); engines that support it:
+                 // k_fwd16 / k_split_reduce16 (bf16 generic), k_dgrad32s (fp32); the others refuse (-1)
 };
 
 struct WgradGeom {
@@ -80,7 +82,7 @@ int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u,
              hipStream_t s, float *stats = nullptr, int *stats_done = nullptr);
 int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s);
 int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const float *dy, const float *wb, float *dx,
-             hipStream_t s);
+             hipStream_t s, int accumulate = 0);
 int pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf, float *const *ub,
                        const int *K, const int *C, const int *T, const int *transposed, hipStream_t s);
 int wino_mode();                          // MVD_WINO: 0 off, 1 F(2,3) along W, 2 F(2x2,3x3) (default)

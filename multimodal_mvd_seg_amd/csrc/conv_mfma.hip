@@ -699,6 +699,7 @@ __global__ __launch_bounds__(512, 1) void k_fwd32s(const FwdGeom g, const Fwd32T
 // Weights: the packed dgrad layout [kk][t][h][c][16] straight from L2, one tap ahead.
 struct Dg2Tile {
     int ntd, nth, ntw, ncb, nitems, C;
+    int acc;  // dx += (the skip connection's second gradient contribution, ops._GradShare)
 };
 __global__ __launch_bounds__(512, 2) void k_dgrad32s(const FwdGeom g, const Dg2Tile tg, const float *__restrict__ dy,
                                                      const float *__restrict__ wb, float *__restrict__ dx) {
@@ -816,13 +817,13 @@ __global__ __launch_bounds__(512, 2) void k_dgrad32s(const FwdGeom g, const Dg2T
         for (int r = 0; r < 16; r++) {
             const int iy = 2 * (oy0 + (r >> 2)) + py, ixu = 2 * (ox0 + (r & 3)) + px;  // wave-uniform
             const size_t uo = ((((size_t)n * g.Dy + iz) * g.Hy + iy) * g.Wy + ixu) * C;
-            if (iz < g.Dy && iy < g.Hy && ixu + 8 * h < g.Wy) xl[uo] = acc[m][r];
+            if (iz < g.Dy && iy < g.Hy && ixu + 8 * h < g.Wy) xl[uo] = tg.acc ? xl[uo] + acc[m][r] : acc[m][r];
         }
     }
 }
 
 int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const float *dy, const float *wb, float *dx,
-             hipStream_t s) {
+             hipStream_t s, int accumulate) {
     if (C % 32 || K % 32 || (((uintptr_t)dy | (uintptr_t)wb) & 15)) return -1;
     if ((long)Do * Ho * Wo * K * 4 >= (1L << 31)) return -1;  // 32-bit byte offsets inside one sample of dy (buffer loads)
     FwdGeom g;
@@ -835,6 +836,7 @@ int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, c
     tg.ntd = (Do + 1) / 2; tg.nth = (Ho + 3) / 4; tg.ntw = (Wo + 7) / 8;
     tg.ncb = C / 32;
     tg.C = C;
+    tg.acc = accumulate;
     const long nitems = (long)N * tg.ntd * tg.nth * tg.ntw * tg.ncb;
     if (nitems > (1L << 30)) return -1;
     tg.nitems = (int)nitems;

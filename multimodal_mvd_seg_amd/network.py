@@ -221,8 +221,11 @@ class PlainConvEncoder(nn.Module):
 
     def forward(self, x):
         ret = []
-        for s in self.stages:
+        last = len(self.stages) - 1
+        for i, s in enumerate(self.stages):
             x = s(x)
+            if self.return_skips and i != last and SHARE_GRADS[0]:
+                ops.share_grad(x)   # a skip: read by the next stage AND by the decoder -> one gradient buffer (ops._GradShare)
             ret.append(x)
         return ret if self.return_skips else ret[-1]
 
@@ -333,6 +336,22 @@ class MI355PlainConvUNet(nn.Module):
         return self.encoder.compute_conv_feature_map_size(input_size) + \
             self.decoder.compute_conv_feature_map_size(input_size)
 
+    def parameters_in_execution_order(self):
+        """Parameters in the order the forward pass first uses them: encoder stages, then per decoder level the transposed
+        conv, the refining convs and the seg layer.  `parameters()` lists them by module type (all stages, all transposed
+        convs, all seg layers).  optim.FlatParams lays the flat gradient buffer out in THIS order, so that a suffix of the
+        buffer is complete exactly when backward has passed the corresponding part of the network: the reducer's buckets
+        (contiguous slices, cut from the end) then fire in backward order while the rest of backward still runs."""
+        out = list(self.encoder.parameters())
+        for up, refine, head in zip(self.decoder.transpconvs, self.decoder.stages, self.decoder.seg_layers):
+            out += list(up.parameters()) + list(refine.parameters()) + list(head.parameters())
+        seen, uniq = set(), []
+        for p in out + list(self.parameters()):   # (anything not covered above keeps its registration order at the end)
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        return uniq
+
 
 def set_precision(module: nn.Module, precision: str):
     """Mixed precision of the reference's autocast path (nnUNetTrainer.py:906; BASELINE cfg 4/5), MI355X style:
@@ -389,3 +408,6 @@ class MVDDualBranchNet(nn.Module):
         o1, f1 = self.branch1(x, True)
         o2, f2 = self.branch2(x, True)
         return o1, o2, f1, f2
+
+    def parameters_in_execution_order(self):
+        return self.branch1.parameters_in_execution_order() + self.branch2.parameters_in_execution_order()

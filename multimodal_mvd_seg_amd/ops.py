@@ -475,6 +475,7 @@ class Conv3dFn(Function):
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, stride):
         _require_cuda(x1, x2, weight, bias)
+        ctx.share1, ctx.share2 = _share_of(x1), (_share_of(x2) if x2 is not None else None)
         x1 = to_ndhwc(x1)
         x2 = to_ndhwc(x2) if x2 is not None else None
         K, C = weight.shape[:2]
@@ -545,7 +546,23 @@ class Conv3dFn(Function):
         sfx = "_bf16" if ctx.bf else ""
         dx1 = dx2 = dw = db = None
         need1, need2 = ctx.needs_input_grad[0], (x2 is not None and ctx.needs_input_grad[1])
-        if need1 or need2:
+        joined = None
+        if need1 and x2 is None and len(ks) == 3:
+            # x1 has a second consumer whose backward already ran (a skip connection: the decoder conv read it through its
+            # second pointer): add this conv's input gradient into that buffer inside the kernel
+            joined = _joinable(ctx.share1, (N, C1, D, H, W), dy.dtype)
+            if joined is not None and not query("mvd_conv3d_dgrad_acc_ok", int(ctx.bf), N, D, H, W, C1, K, i3(ks), i3(stride)):
+                joined = None
+        if joined is not None:
+            if ctx.bf:
+                ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C1), dev)
+                call("mvd_conv3d_dgrad_bf16_acc", _p(dy), _p(wb), _p(joined), C1, N, D, H, W, K, i3(ks), i3(stride), _p(ws),
+                     ws.numel(), _stream())
+            else:
+                call("mvd_conv3d_dgrad_acc", _p(dy), _p(wb), _p(joined), C1, N, D, H, W, K, i3(ks), i3(stride), _stream())
+            ctx.share1.buf = None   # consumed
+            need1 = False           # (None to autograd: the contribution already sits in the first consumer's tensor)
+        elif need1 or need2:
             dx1 = empty_cl3d((N, C1, D, H, W), dev, dy.dtype)
             dx2 = empty_cl3d((N, C2, D, H, W), dev, dy.dtype) if x2 is not None else None
             ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C1 + C2), dev)
@@ -555,6 +572,10 @@ class Conv3dFn(Function):
             else:
                 call("mvd_conv3d_dgrad_wino", _p(dy), _p(wb), _p(ub), _p(dx1), C1, _p(dx2), C2, N, D, H, W, K, i3(ks),
                      i3(stride), _p(ws), ws.numel(), _stream())
+            if need1:
+                _publish(ctx.share1, dx1)
+            if need2:
+                _publish(ctx.share2, dx2)
         if ctx.needs_input_grad[2]:
             T = ks[0] * ks[1] * ks[2]
             weight, bias = ctx.params

@@ -87,11 +87,23 @@ class BucketedGradReducer:
         ends = [o + ((p.numel() + self.fp.ALIGN - 1) // self.fp.ALIGN) * self.fp.ALIGN
                 for p, o in zip(self.fp.params, self.fp.offsets)]
         self.buckets = []  # (start, end, [param indices])
+        # Cut from the END of the buffer (the parameters backward completes first) into >= bucket_bytes pieces; the piece
+        # reduced LAST (the network's first layers, complete only when backward ends: its all-reduce cannot hide behind
+        # anything) is kept to <= tail_bytes, so that what is exposed after backward is one small collective.
+        tail_bytes = min(bucket_bytes, 4 * 1024 * 1024)
+        sizes = [self.fp.params[i].numel() * 4 for i in range(n)]
+        prefix = [0] * (n + 1)   # bytes of parameters 0 .. i-1
+        for i in range(n):
+            prefix[i + 1] = prefix[i] + sizes[i]
         cur_end, cur_idx, cur_bytes = ends[-1] if n else 0, [], 0
         for i in range(n - 1, -1, -1):
             cur_idx.append(i)
-            cur_bytes += self.fp.params[i].numel() * 4
-            if cur_bytes >= bucket_bytes or i == 0:
+            cur_bytes += sizes[i]
+            left = prefix[i]          # bytes still in front of parameter i
+            close = cur_bytes >= bucket_bytes or i == 0
+            if not close and 0 < left <= tail_bytes and cur_bytes + left > tail_bytes:
+                close = True          # what is left fits the tail bucket, together with this piece it would not
+            if close:
                 self.buckets.append((self.fp.offsets[i], cur_end, list(cur_idx)))
                 cur_end, cur_idx, cur_bytes = self.fp.offsets[i], [], 0
         self.bucket_of = {}

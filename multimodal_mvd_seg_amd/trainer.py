@@ -189,7 +189,11 @@ class nnUNetTrainerMI355(object):
         self.was_initialized = True
 
     def configure_optimizers(self):
-        optimizer = FusedSGDNesterov(FlatParams(list(self.network.parameters())), self.initial_lr,
+        # flat buffers in forward-execution order (network.parameters_in_execution_order): the gradient all-reduce buckets --
+        # contiguous slices cut from the end -- then complete in backward order (parallel.BucketedGradReducer)
+        order = getattr(self.network, "parameters_in_execution_order", None)
+        params = order() if order is not None else list(self.network.parameters())
+        optimizer = FusedSGDNesterov(FlatParams(params), self.initial_lr,
                                      weight_decay=self.weight_decay, momentum=0.99, nesterov=True, max_grad_norm=12)
         lr_scheduler = PolyLRScheduler(optimizer, self.initial_lr, self.num_epochs)
         return optimizer, lr_scheduler

@@ -277,10 +277,13 @@ def _set_kernel(which):
     call("mvd_set_bf16_zmarch_kernel", which)
 
 
-@pytest.mark.parametrize("C1,C2,N,D,H,W", [(32, 0, 2, 52, 60, 44), (32, 0, 1, 33, 70, 97), (32, 0, 1, 128, 64, 64),
-                                            (32, 32, 1, 40, 44, 70), (32, 32, 2, 64, 64, 64), (64, 0, 1, 36, 72, 66),
-                                            (32, 32, 1, 17, 41, 130)])
-def test_fwd16y_exact_integer_data_forward_and_input_gradient(C1, C2, N, D, H, W):
+@pytest.mark.parametrize("C1,C2,K,N,D,H,W", [(32, 0, 32, 2, 52, 60, 44), (32, 0, 32, 1, 33, 70, 97), (32, 0, 32, 1, 128, 64, 64),
+                                              (32, 32, 32, 1, 40, 44, 70), (32, 32, 32, 2, 64, 64, 64), (64, 0, 32, 1, 36, 72, 66),
+                                              (32, 32, 32, 1, 17, 41, 130),
+                                              # 64 produce channels (one row group x four channel quarters): the 64^3 stage
+                                              (64, 0, 64, 2, 64, 64, 64), (64, 0, 64, 1, 40, 44, 70), (32, 0, 64, 1, 36, 72, 66),
+                                              (64, 64, 64, 1, 64, 64, 64), (32, 32, 64, 1, 33, 70, 97)])
+def test_fwd16y_exact_integer_data_forward_and_input_gradient(C1, C2, K, N, D, H, W):
     """k_fwd16y on small-integer data: every product and fp32 partial sum is an exact integer, so forward and input gradient
     must equal torch's exact fp32 convolution rounded once to bf16, bit for bit -- 32 reduce channels, 32 + 32 through two
     pointers (the eliminated torch.cat, UNetDecoder.py:107; its gradient = two launches into two tensors), 64 in one tensor;
@@ -290,7 +293,7 @@ def test_fwd16y_exact_integer_data_forward_and_input_gradient(C1, C2, N, D, H, W
     g = torch.Generator().manual_seed(D * 7 + H + C2)
     ints = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=g).float()
     C = C1 + C2
-    x, w, b = ints((N, C, D, H, W), -2, 2), ints((32, C, 3, 3, 3), -2, 2), ints((32,), -3, 3)
+    x, w, b = ints((N, C, D, H, W), -2, 2), ints((K, C, 3, 3, 3), -2, 2), ints((K,), -3, 3)
     xr = x.clone().requires_grad_()
     ref = F.conv3d(xr, w, b, 1, 1)
     gy = ints(tuple(ref.shape), -1, 1)

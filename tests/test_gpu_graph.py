@@ -173,3 +173,36 @@ print("RCCL_IN_GRAPH_OK")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "RCCL_IN_GRAPH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gradient_sharing_of_two_consumer_tensors_matches_autograds_own_sum(precision):
+    """ops._GradShare: the skip connections (next encoder stage + decoder conv, UNetDecoder.py:106-108) and the decoder stage
+    outputs (seg head + next up-sampling) get ONE gradient buffer; the second consumer adds inside its kernel (k_dgrad32s /
+    k_fwd16 epilogue read-modify-write, k_seghead_dx4 accumulate) instead of autograd's elementwise add.  fp32: a + b either
+    way -> bit-identical parameters after two steps; bf16: the skip path is bit-identical (fp32 add of two bf16 values, one
+    rounding, as torch's add), the seg-head path saves one rounding -> equal to bf16 resolution."""
+    from multimodal_mvd_seg_amd import network
+    res = []
+    for share in (True, False):
+        network.SHARE_GRADS[0] = share
+        try:
+            tr = _make("nnUNetTrainerMI355", precision, False, patch=(64, 64, 64))
+            if res:
+                tr.network.load_state_dict(res[0][2])
+                tr.optimizer.fp.invalidate_packs()
+            sd0 = {k: v.clone() for k, v in tr.network.state_dict().items()}
+            bs = _batches(tr, 2)
+            ls = [float(tr.train_step(b)["loss"]) for b in bs]
+            res.append((ls, [p.detach().clone() for p in tr.network.parameters()], sd0))
+        finally:
+            network.SHARE_GRADS[0] = True
+    (la, pa, _), (lb, pb, _) = res
+    if precision == "fp32":
+        assert la == lb
+        for u, v in zip(pa, pb):
+            assert torch.equal(u, v)
+    else:
+        assert abs(la[1] - lb[1]) <= 2e-3 * abs(lb[1])
+        worst = max(float((u - v).abs().max()) for u, v in zip(pa, pb))
+        assert worst <= 2e-3, worst

@@ -340,3 +340,34 @@ def test_conv_block_refuses_plans_it_would_silently_mis_execute():
                 {"norm_op_kwargs": {'eps': 1e-5, 'affine': False}}):
         with pytest.raises(NotImplementedError):
             ConvDropoutNormReLU(nn.Conv3d, 4, 8, 3, 1, True, **{**ok, **bad})
+
+
+def test_flat_layout_follows_execution_order_and_the_last_reduced_bucket_is_small():
+    """DDP overlap (nnUNetTrainer.py:220-222 wraps the network in DDP, whose buckets fire in gradient-ready order): the flat
+    gradient buffer is laid out in forward-execution order, so contiguous buckets cut from its end complete in backward
+    order; the bucket reduced last (the first encoder stages, complete only when backward ends) is <= 4 MB."""
+    net, c = build("cfg2")
+    order = net.parameters_in_execution_order()
+    assert len(order) == len(list(net.parameters())) and len({id(p) for p in order}) == len(order)
+    names = {id(p): n for n, p in net.named_parameters()}
+    seq = [names[id(p)] for p in order]
+    first_dec = next(i for i, n in enumerate(seq) if n.startswith("decoder."))
+    assert all(n.startswith("encoder.") for n in seq[:first_dec])
+    # per decoder level: transposed conv, refining convs, seg layer -- contiguous, level 0 (bottleneck side) first
+    lv = [(("transpconvs", "stages", "seg_layers").index(n.split(".")[1]), int(n.split(".")[2])) for n in seq[first_dec:]]
+    levels = [l for _k, l in lv]
+    assert levels == sorted(levels)
+    for L in set(levels):
+        kinds = [k for k, l in lv if l == L]
+        assert kinds == sorted(kinds)
+    fp = optim.FlatParams(order)
+    assert [id(p) for p in fp.params] == [id(p) for p in order]
+    red = parallel.BucketedGradReducer(fp, 25 * 1024 * 1024)
+    sizes = [(e - s) * 4 for s, e, _ in red.buckets]
+    assert sum(len(idx) for _s, _e, idx in red.buckets) == len(order)
+    assert red.buckets[0][1] == fp.offsets[-1] + ((order[-1].numel() + 3) // 4) * 4   # the first bucket ends the buffer
+    assert red.buckets[-1][0] == 0 and sizes[-1] <= 4 * 1024 * 1024                  # the last one starts it and is small
+    assert all(s >= 25 * 1024 * 1024 for s in sizes[:-2])
+    # buckets are contiguous and ordered from the end of the buffer
+    for (s0, e0, _), (s1, e1, _) in zip(red.buckets[:-1], red.buckets[1:]):
+        assert e1 == s0
