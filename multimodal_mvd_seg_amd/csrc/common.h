@@ -38,6 +38,17 @@ inline hipStream_t as_stream(void *s) {
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// "dynamic LDS limit raised for this kernel" flags are per DEVICE (hipFuncSetAttribute acts on the current device's copy
+// of the code object; ADVICE r2: a process-wide flag left a second GPU of the same process without the attribute).
+struct PerDeviceFlag {
+    unsigned char done[64] = {};
+    bool &operator()() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        return reinterpret_cast<bool &>(done[dev]);
+    }
+};
+
 // A value loaded from memory, made "arrived" HERE: the empty volatile asm is a use the compiler must wait for, once and
 // unconditionally.  Without it a bias loaded at the top of an epilogue has its first use inside the predicated store
 // blocks, every such block gets an s_waitcnt vmcnt(0), and that also waits for the previous block's STORE: the stores

@@ -426,14 +426,14 @@ static int launch_fwd16(const FwdGeom &g, Fwd16Tile &tg, const unsigned short *a
     auto kern = k_fwd16<NT, MT, TG, XR, SWZ, NW>;
     const size_t lds = (size_t)XR * (NW * 16) * (SWZ ? 64 : 80) + 2 * (size_t)TG * 4 * (32 * NT) * 16 + 256;  // + tap tables
     if (lds > LDS_LIMIT16) return -1;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceFlag configured;
+    if (!configured()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)LDS_LIMIT16) != hipSuccess) {
             set_error("conv fwd16: cannot raise the dynamic LDS limit");
             return 1;
         }
-        configured = true;
+        configured() = true;
     }
     const int K = g.K1 + g.K2;
     tg.nkb = K / (32 * NT);
@@ -1526,15 +1526,15 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
             const int fz = (want_stats ? 1 : 0) | (want_pro ? 2 : 0);
             if (fz == 2) kfn = k_fwd16z<0, 2>;
             if (fuse && fuse->ntiles) *fuse->ntiles = want_stats ? tz.nzc * tz.nty * tz.ntx : 0;
-            static bool configured_z[4] = {false, false, false, false};
-            if (!configured_z[fz]) {
+            static PerDeviceFlag configured_z[4];
+            if (!configured_z[fz]()) {
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z_LDS);
                 if (e != hipSuccess) {
                     set_error("conv fwd16z: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
                     return 1;
                 }
-                configured_z[fz] = true;
+                configured_z[fz]() = true;
             }
             const int per_xcd = (tz.nitems + 7) / 8;
             tz.kp = g.K1 + g.K2;
@@ -1553,14 +1553,14 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
         if (two_out) return -1;
         static const int use_r = getenv("MVD_FWD16R") ? atoi(getenv("MVD_FWD16R")) : 0;
         if (ok && use_r) {
-            static bool configured_r = false;
-            if (!configured_r) {
+            static PerDeviceFlag configured_r;
+            if (!configured_r()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd16r), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)LDS_LIMIT16) != hipSuccess) {
                     set_error("conv fwd16r: cannot raise the dynamic LDS limit");
                     return 1;
                 }
-                configured_r = true;
+                configured_r() = true;
             }
             hipLaunchKernelGGL(k_fwd16r, dim3((unsigned)ncu), dim3(Q_TPB), 3 * (size_t)R_BUF, s, g, tq, a1, w, bias, y1);
             return check_launch("conv fwd16r (persistent bf16 mfma, LDS-DMA halo)");
@@ -1572,14 +1572,14 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
             static const kq_t kq[16] = {k_fwd16q<0>, k_fwd16q<1>, k_fwd16q<2>, k_fwd16q<3>, k_fwd16q<4>, k_fwd16q<5>,
                                         k_fwd16q<6>, k_fwd16q<7>, k_fwd16q<8>, k_fwd16q<9>, k_fwd16q<10>, k_fwd16q<11>,
                                         k_fwd16q<12>, k_fwd16q<13>, k_fwd16q<14>, k_fwd16q<15>};
-            static bool configured_q = false;
-            if (!configured_q) {
+            static PerDeviceFlag configured_q;
+            if (!configured_q()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq[dbgq]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)LDS_LIMIT16) != hipSuccess) {
                     set_error("conv fwd16q: cannot raise the dynamic LDS limit");
                     return 1;
                 }
-                configured_q = true;
+                configured_q() = true;
             }
             hipLaunchKernelGGL(kq[dbgq], dim3((unsigned)ncu), dim3(Q_TPB), 2 * (size_t)Q_HALO, s, g, tq, a1, w, bias, y1);
             return check_launch("conv fwd16q (persistent bf16 mfma, weights in registers)");
@@ -1590,14 +1590,14 @@ static int launch_fwd16p(const FwdGeom &g, const unsigned short *a1, const unsig
     if (fuse && fuse->in_scale) return -1;
     if (fuse && fuse->ntiles) *fuse->ntiles = 0;
     const size_t lds = (size_t)P_WB + 2 * (size_t)P_HALO;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceFlag configured;
+    if (!configured()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd16p), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)LDS_LIMIT16) != hipSuccess) {
             set_error("conv fwd16p: cannot raise the dynamic LDS limit");
             return 1;
         }
-        configured = true;
+        configured() = true;
     }
     static const int dbg = getenv("MVD_FWD16P_DBG") ? atoi(getenv("MVD_FWD16P_DBG")) : 0;
     hipLaunchKernelGGL(k_fwd16p, dim3((unsigned)ncu), dim3(P_TPB), lds, s, g, tg, a1, w, bias, y1, dbg);

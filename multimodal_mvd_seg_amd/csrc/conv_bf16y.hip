@@ -446,15 +446,15 @@ int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned sho
     const int fz = (want_stats ? 1 : 0) | (want_pro ? 2 : 0), ki = KQ == 2 ? 0 : 1;
     const ky_t kfn = kern[ki][nch - 1][fz];
     const size_t lds = 2 * (size_t)nch * (KQ == 2 ? y_chunk(2) : y_chunk(4));
-    static bool configured[2][2][4] = {};
-    if (!configured[ki][nch - 1][fz]) {
+    static PerDeviceFlag configured[2][2][4];
+    if (!configured[ki][nch - 1][fz]()) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)(2 * 2 * y_chunk(2)));
         if (e != hipSuccess) {
             set_error("conv fwd16y: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
             return 1;
         }
-        configured[ki][nch - 1][fz] = true;
+        configured[ki][nch - 1][fz]() = true;
     }
     const int per_xcd = (tz.nitems + 7) / 8;
     tz.kp = g.K1 + g.K2;

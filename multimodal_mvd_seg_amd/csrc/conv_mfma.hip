@@ -881,14 +881,14 @@ static int launch_fwd32s(const FwdGeom &g, const float *a1, const float *a2, con
     if (nitems > (1L << 30)) return -1;
     tg.nitems = (int)nitems;
     const size_t lds = (size_t)tg.nslots * 36 * sizeof(float);
-    static bool cfgd = false;
-    if (!cfgd) {
+    static PerDeviceFlag cfgd;
+    if (!cfgd()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd32s), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)LDS_LIMIT) != hipSuccess) {
             set_error("conv fwd (stride 2): cannot raise the dynamic LDS limit");
             return 1;
         }
-        cfgd = true;
+        cfgd() = true;
     }
     const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
     hipLaunchKernelGGL(k_fwd32s, dim3(grid), dim3(512), lds, s, g, tg, a1, a2, w, bias, y1, y2);
@@ -932,14 +932,14 @@ static int launch_fwd32(const FwdGeom &g, Fwd32Tile &tg, const float *a1, const 
     auto kern = k_fwd32<NT, MT, TG>;
     constexpr int XR = MT == 2 ? 19 : 12;
     const size_t lds = ((size_t)XR * 32 * 36 + 2 * (size_t)TG * 2 * (32 * NT) * 20) * 4;
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceFlag configured;
+    if (!configured()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)LDS_LIMIT) != hipSuccess) {
             set_error("conv fwd32 (mfma): cannot raise the dynamic LDS limit");
             return 1;
         }
-        configured = true;
+        configured() = true;
     }
     const int K = g.K1 + g.K2;
     tg.nkb = K / (32 * NT);
@@ -2859,14 +2859,14 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     {                                                                                                              \
         auto kern = k_wgrad_mfma<TPW, NA, NB, SH>;                                                                 \
         const size_t lds = (size_t)(NA + NB) * 8192 * (db_mfma ? 2 : 1);                                           \
-        static bool cfgd = false;                                                                                  \
-        if (!cfgd) {                                                                                               \
+        static PerDeviceFlag cfgd;                                                                                  \
+        if (!cfgd()) {                                                                                               \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)LDS_LIMIT) != hipSuccess) {                                               \
                 set_error("conv wgrad (mfma): cannot raise the dynamic LDS limit");                                \
                 return 1;                                                                                          \
             }                                                                                                      \
-            cfgd = true;                                                                                           \
+            cfgd() = true;                                                                                           \
         }                                                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, g, tg, a1, a2, b, partial, (SH) == 1 ? pbias_g : nullptr); \
     }
@@ -2906,24 +2906,24 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         else WG16(7, NA, NB, SH);             \
     }
         if (cfg == 2) {  // (chosen only for 27 taps, stride 1, one dy slot for all taps: sameB, tpw == 7)
-            static bool cfgd_big = false;
-            if (!cfgd_big) {
+            static PerDeviceFlag cfgd_big;
+            if (!cfgd_big()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad16<7, 10, 4, 1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) {
                     set_error("conv wgrad (bf16 mfma): cannot raise the dynamic LDS limit");
                     return 1;
                 }
-                cfgd_big = true;
+                cfgd_big() = true;
             }
             if (tri) {
-                static bool cfgd_tri = false;
-                if (!cfgd_tri) {
+                static PerDeviceFlag cfgd_tri;
+                if (!cfgd_tri()) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad16<7, 10, 4, 1, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess) {
                         set_error("conv wgrad (bf16 mfma): cannot raise the dynamic LDS limit");
                         return 1;
                     }
-                    cfgd_tri = true;
+                    cfgd_tri() = true;
                 }
                 WG16T(7, 10, 4, 1, true);
             } else {
@@ -2975,14 +2975,14 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                 static const int db12 = getenv("MVD_WGRAD_DB") ? atoi(getenv("MVD_WGRAD_DB")) : 1;
                 auto kern2 = w8 == 12 ? (db12 ? k_wgrad_wino2w12<5, 2, true> : k_wgrad_wino2w12<5, 2, false>)
                                       : (w8 ? k_wgrad_wino2w8<7, 2> : k_wgrad_wino2<13, 4>);
-                static bool cfgd_w2 = false;
-                if (!cfgd_w2) {
+                static PerDeviceFlag cfgd_w2;
+                if (!cfgd_w2()) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)LDS_LIMIT) != hipSuccess) {
                         set_error("conv wgrad (winograd 2-D): cannot raise the dynamic LDS limit");
                         return 1;
                     }
-                    cfgd_w2 = true;
+                    cfgd_w2() = true;
                 }
                 hipLaunchKernelGGL(kern2, grid, dim3(w8 == 12 ? 768 : (w8 ? 512 : 256)),
                                    w8 == 12 ? (db12 ? (size_t)2 * (4 * 100 + 2 * 64) * 128 : (size_t)(5 + 2) * 12288)
@@ -2999,14 +2999,14 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                 return check_launch("conv wgrad reduce (winograd 2-D)");
             }
             auto kern = tg.TW == 8 ? k_wgrad_wino<13, 4, 4> : k_wgrad_wino<13, 4, 2>;
-            static bool cfgd_w[2] = {false, false};
-            if (!cfgd_w[tg.TW == 8]) {
+            static PerDeviceFlag cfgd_w[2];
+            if (!cfgd_w[tg.TW == 8]()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)LDS_LIMIT) != hipSuccess) {
                     set_error("conv wgrad (winograd): cannot raise the dynamic LDS limit");
                     return 1;
                 }
-                cfgd_w[tg.TW == 8] = true;
+                cfgd_w[tg.TW == 8]() = true;
             }
             hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)(13 + 4) * 4096, s, g, tg, a1, a2, b, partial);
             if (check_launch("conv wgrad (winograd)")) return 1;

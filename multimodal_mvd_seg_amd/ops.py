@@ -622,6 +622,10 @@ class NarrowInputConv3dBf16Fn(Function):
         _require_cuda(x, weight, bias)
         if x.dtype != torch.float32:
             raise RuntimeError("narrow-input bf16 conv: the network input must be fp32")
+        if ctx.needs_input_grad[0]:
+            # (the backward of this layer has no input-gradient kernel; say so instead of returning None)
+            raise RuntimeError("narrow-input bf16 conv: the gradient with respect to the network input is not on the path "
+                               "(detach the input, or run the layer in fp32)")
         K, C = weight.shape[:2]
         if tuple(weight.shape[2:]) != (3, 3, 3) or K % 32 != 0 or C > 8 or x.shape[1] != C:
             raise RuntimeError("narrow-input bf16 conv: needs a 3x3x3 conv with <= 8 input and a multiple of 32 output channels")

@@ -4,7 +4,8 @@ Compiles, from the sources where they lie under /root/reference (never copied), 
 TopologyLayer persistence extension
 (nnUNet/nnunetv2/training/topologylayer/functional/persistence/{cocycle,complex,hom,cohom,pybind}.cpp)
 with g++ through torch.utils.cpp_extension (the reference ships no build script of its own for it).
-Outputs go only to oracle/_ref/ (git-ignored, NOT gpurun-ignored: the built .so travels to the GPU box).
+Outputs go only to oracle/_ref/ (git-ignored AND gpurun-ignored since round 3: it stays in the build container; the GPU
+box sees its outputs through tests/golden/persistence_grid.json).
 Used by tests/ and tools/make_golden.py to pin oracle/cc_oracle.c; the product path never loads it.
 """
 import os
