@@ -788,6 +788,12 @@ static int dgrad_bf16_impl(const uint16_t *dy, const uint16_t *wb, uint16_t *dx1
         od[a] = out_dim(dims[a], ksize[a], stride[a]);
         pad[a] = (ksize[a] - 1) / 2;
     }
+    // 3x3x3 stride-2 conv with 32-multiple channels and a single input: all eight parity classes in one kernel
+    if (g_engine_mode == 0 && C2 == 0 && ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3 && stride[0] == 2 && stride[1] == 2 &&
+        stride[2] == 2 && (long)N * od[0] * od[1] * od[2] >= 512) {
+        int r = dgrad16s(N, D, H, W, C1, K, od[0], od[1], od[2], dy, wb, dx1, as_stream(stream), acc);
+        if (r >= 0) return r;
+    }
     // one launch per output-parity class (1 class per stride-1 axis, 2 per stride-2 axis)
     for (int pd = 0; pd < stride[0]; pd++)
         for (int ph = 0; ph < stride[1]; ph++)

@@ -417,6 +417,163 @@ __global__ void k_split_reduce16(const FwdGeom g, const float *__restrict__ part
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stride-2 input gradient
+// bf16 twin of k_dgrad32s (conv_mfma.hip): dx of a 3x3x3 stride-2 pad-1 conv, all eight output-parity classes from ONE
+// staged dy tile.  The per-class launches of the gather engine re-read dy eight times and run 1- and 2-tap classes as whole
+// launches (0.37 ms for 64 -> 32 at 128^3, whose traffic and MFMA work are ~0.07 ms each).  Workgroup = 8 waves on a
+// 3 x 5 x 9 dy tile (2 x 4 x 8 positions j + the odd classes' +1 neighbours) per 32-channel reduce chunk; wave w takes
+// class w on the positions of plane oz0 and class 7 - w on plane oz0 + 1 (6 or 9 tap groups per wave).  Swapped product
+// D^T = W^T dy^T on v_mfma_f32_32x32x16_bf16: A = packed weights straight from L2 (one tap ahead), B = dy fragment from the
+// LDS tile ([slot][64 B], 16-byte parts XORed by (slot >> 2) & 3: 2-way conflicts at worst); a lane ends with 16
+// channels of ONE dx voxel and stores two 16-byte images (permlane32 exchange).  FwdGeom::acc adds into dx.
+struct Dg16Tile {
+    int ntd, nth, ntw, ncb, nitems, C;
+    int acc;
+};
+__global__ __launch_bounds__(512, 2) void k_dgrad16s(const FwdGeom g, const Dg16Tile tg, const unsigned short *__restrict__ dy,
+                                                     const unsigned short *__restrict__ wb, unsigned short *__restrict__ dx) {
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[135 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int per_xcd = (tg.nitems + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= tg.nitems) return;
+    unsigned r_ = (unsigned)item;
+    const int cb = (int)(r_ % (unsigned)tg.ncb); r_ /= (unsigned)tg.ncb;
+    const int tw_ = (int)(r_ % (unsigned)tg.ntw); r_ /= (unsigned)tg.ntw;
+    const int th_ = (int)(r_ % (unsigned)tg.nth); r_ /= (unsigned)tg.nth;
+    const int td_ = (int)(r_ % (unsigned)tg.ntd);
+    const int n = (int)(r_ / (unsigned)tg.ntd);
+    // g.Di/Hi/Wi = dy grid (conv output), g.Dy/Hy/Wy = dx grid (conv input), g.C1 = K (reduce), tg.C = channels of dx
+    const int K = g.C1, C = tg.C;
+    const int nch = K >> 5;
+    const int oz0 = td_ * 2, oy0 = th_ * 4, ox0 = tw_ * 8;
+    // packed dgrad weights [chunk][tap][s][h][c][8]: lane (c = i, h) of k-step s
+    const unsigned short *wlane = wb + ((size_t)h * C + cb * 32 + i) * 8;
+    const size_t wstep = (size_t)2 * C * 8, wtap = 2 * wstep;
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+    for (int kk = 0; kk < nch; kk++) {
+        __syncthreads();
+        {
+            const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned short *>(dy + (size_t)n * g.Di * g.Hi * g.Wi * K + kk * 32), 0, 0x7fffffff, 0x00020000);
+            uint4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int idx = tid + u * 512;
+                const int slot = idx >> 2, part = idx & 3;
+                const int ez = slot / 45, rem = slot - ez * 45;
+                const int ey = rem / 9, ex = rem - ey * 9;
+                const int oz = oz0 + ez, oy = oy0 + ey, ox = ox0 + ex;
+                const bool ok = idx < 135 * 4 && oz < g.Di && oy < g.Hi && ox < g.Wi;
+                const unsigned o = ok ? (unsigned)(((oz * g.Hi + oy) * g.Wi + ox) * K + part * 8) * 2u : 0xffffffffu;
+                v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)o, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int idx = tid + u * 512;
+                const int slot = idx >> 2, part = idx & 3;
+                if (idx < 135 * 4) *reinterpret_cast<uint4 *>(Xs + slot * 64 + ((part ^ ((slot >> 2) & 3)) << 4)) = v[u];
+            }
+        }
+        __syncthreads();
+        const unsigned short *wc = wlane + (size_t)kk * 27 * wtap;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int q = m ? 7 - wave : wave;
+            const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+            const int slot0 = (m * 5 + (i >> 3)) * 9 + (i & 7);
+            // the class's taps: per axis (t = 1, d = 0) for an even coordinate, (t = 0, d = 1) and (t = 2, d = 0) for an odd one
+            const int ntq = 1 << (pz + py + px);
+            auto tap_of = [&](int j, int &t, int &so) {
+                const int bz = pz ? (j >> (py + px)) & 1 : 0, by = py ? (j >> px) & 1 : 0, bx = px ? j & 1 : 0;
+                const int tz = pz ? (bz ? 2 : 0) : 1, ty = py ? (by ? 2 : 0) : 1, tx = px ? (bx ? 2 : 0) : 1;
+                const int dz = (pz && !bz) ? 1 : 0, dyy = (py && !by) ? 1 : 0, dxx = (px && !bx) ? 1 : 0;
+                t = (tz * 3 + ty) * 3 + tx;
+                so = (dz * 5 + dyy) * 9 + dxx;
+            };
+            uint4 wv[2][2];
+            int t0, so0;
+            tap_of(0, t0, so0);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) wv[0][s2] = *reinterpret_cast<const uint4 *>(wc + (size_t)t0 * wtap + s2 * wstep);
+            for (int j = 0; j < ntq; j += 2) {  // two taps per trip: static buffer indices (ntq is 1, 2, 4 or 8)
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (j + u < ntq) {  // wave-uniform
+                        int t, so, tn, son;
+                        tap_of(j + u, t, so);
+                        tap_of(j + u + 1 < ntq ? j + u + 1 : j + u, tn, son);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; s2++)
+                            wv[(u + 1) & 1][s2] = *reinterpret_cast<const uint4 *>(wc + (size_t)tn * wtap + s2 * wstep);
+                        const int slot = slot0 + so;
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; s2++) {
+                            const uint4 xq = *reinterpret_cast<const uint4 *>(Xs + slot * 64 + ((((s2 << 1) | h) ^ ((slot >> 2) & 3)) << 4));
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(&wv[u][s2]),
+                                                                            *reinterpret_cast<const bf16x8 *>(&xq), acc[m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // lane (i, h) holds, per M tile m, channels (r & 3) + 8 (r >> 2) + 4 h of dx voxel 2 j + p, j = (oz0 + m, oy0 + (i >> 3),
+    // ox0 + (i & 7)): two 16-byte images after the lane-half exchange
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int q = m ? 7 - wave : wave;
+        const int pz = q >> 2, py = (q >> 1) & 1, px = q & 1;
+        const int iz = 2 * (oz0 + m) + pz, iy = 2 * (oy0 + (i >> 3)) + py, ix = 2 * (ox0 + (i & 7)) + px;
+        const bool inside = iz < g.Dy && iy < g.Hy && ix < g.Wy;
+        const size_t ov = (((size_t)n * g.Dy + iz) * g.Hy + iy) * g.Wy + ix;
+#pragma unroll
+        for (int kp = 0; kp < 2; kp++) {
+            uint2 pk[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int rg = 2 * kp + e;
+                pk[e] = pack_bf16x4(acc[m][rg * 4 + 0], acc[m][rg * 4 + 1], acc[m][rg * 4 + 2], acc[m][rg * 4 + 3]);
+            }
+            const uint4 img = pair_store_image(pk[0], pk[1]);
+            if (inside) {
+                uint4 *dst = reinterpret_cast<uint4 *>(dx + ov * C + cb * 32 + 16 * kp + 8 * h);
+                *dst = tg.acc ? add_bf16x8(img, *dst) : img;
+            }
+        }
+    }
+}
+
+int dgrad16s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const unsigned short *dy, const unsigned short *wb,
+             unsigned short *dx, hipStream_t s, int accumulate) {
+    static const int on = getenv("MVD_DGRAD16S") ? atoi(getenv("MVD_DGRAD16S")) : 1;
+    if (!on || C % 32 || K % 32 || (((uintptr_t)dy | (uintptr_t)wb | (uintptr_t)dx) & 15)) return -1;
+    if ((long)Do * Ho * Wo * K * 2 >= (1L << 31)) return -1;  // 32-bit byte offsets inside one sample of dy (buffer loads)
+    FwdGeom g;
+    memset(&g, 0, sizeof(g));
+    g.N = N;
+    g.Di = Do; g.Hi = Ho; g.Wi = Wo;
+    g.Dy = D; g.Hy = H; g.Wy = W;
+    g.C1 = K;
+    Dg16Tile tg;
+    tg.ntd = (Do + 1) / 2; tg.nth = (Ho + 3) / 4; tg.ntw = (Wo + 7) / 8;
+    tg.ncb = C / 32;
+    tg.C = C;
+    tg.acc = accumulate;
+    const long nitems = (long)N * tg.ntd * tg.nth * tg.ntw * tg.ncb;
+    if (nitems > (1L << 30)) return -1;
+    tg.nitems = (int)nitems;
+    const unsigned grid = (unsigned)(((nitems + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_dgrad16s, dim3(grid), dim3(512), 0, s, g, tg, dy, wb, dx);
+    return check_launch("conv dgrad bf16 (stride 2, fused parity classes)");
+}
+
 static const size_t LDS_LIMIT16 = 160 * 1024;
 
 template <int NT, int MT, int TG, int XR, bool SWZ, int NW = 4>

@@ -83,6 +83,9 @@ int fwd_wino(const FwdGeom &g, const float *a1, const float *a2, const float *u,
 int pack_weight_wino(const float *w, float *uf, float *ub, int K, int C, hipStream_t s);
 int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const float *dy, const float *wb, float *dx,
              hipStream_t s, int accumulate = 0);
+// bf16 twin (conv_bf16.hip): all eight parity classes of a 3x3x3 stride-2 conv's input gradient from one staged dy tile
+int dgrad16s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const unsigned short *dy, const unsigned short *wb,
+             unsigned short *dx, hipStream_t s, int accumulate = 0);
 int pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf, float *const *ub,
                        const int *K, const int *C, const int *T, const int *transposed, hipStream_t s);
 int wino_mode();                          // MVD_WINO: 0 off, 1 F(2,3) along W, 2 F(2x2,3x3) (default)

@@ -344,3 +344,37 @@ def test_fwd16y_random_data_matches_fp64_and_the_other_kernel(C1, C2):
     # the two kernels accumulate the 27 x C products in different orders: equal up to one bf16 rounding
     d = (ys[0].float() - ys[1].float()).abs()
     assert float(d.max()) <= 2.0 ** -7 * float(ys[0].float().abs().max())
+
+
+@pytest.mark.parametrize("C,K,N,D,H,W", [(32, 64, 2, 40, 44, 36), (64, 128, 1, 33, 41, 38), (32, 32, 1, 17, 130, 23),
+                                          (128, 256, 2, 16, 16, 16)])
+def test_fused_stride2_input_gradient_bf16_exact_integer_data_and_accumulate_form(C, K, N, D, H, W):
+    """k_dgrad16s: the input gradient of a 3x3x3 stride-2 conv (all eight output-parity classes from one staged dy tile) on
+    small-integer data == torch's exact result rounded once to bf16, bit for bit, on even and odd extents; the accumulating
+    form (ops._GradShare: dx += ...) == old + gradient, exactly (integers)."""
+    from multimodal_mvd_seg_amd import ops
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    g = torch.Generator().manual_seed(C + D)
+    ints = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=g).float()
+    x, w = ints((N, C, D, H, W), -2, 2), ints((K, C, 3, 3, 3), -2, 2)
+    xr = x.clone().requires_grad_()
+    ref = F.conv3d(xr, w, None, 2, 1)
+    gy = ints(tuple(ref.shape), -1, 1)
+    ref.backward(gy)
+    gx = x.to(DEV).to(BF).contiguous(memory_format=CL).requires_grad_()
+    gw = w.to(DEV).requires_grad_()
+    y = ops.Conv3dFn.apply(gx, None, gw, None, (2, 2, 2))
+    assert torch.equal(y.detach().cpu(), ref.detach().to(BF))
+    dyd = gy.to(DEV).to(BF).contiguous(memory_format=CL)
+    y.backward(dyd)
+    assert torch.equal(gx.grad.cpu(), xr.grad.to(BF)), "dx"
+    assert torch.equal(gw.grad.cpu(), w.grad if False else torch.autograd.grad(F.conv3d(x, w.requires_grad_(), None, 2, 1), w, gy)[0]), "dw"
+    # accumulate form through the C ABI
+    assert query("mvd_conv3d_dgrad_acc_ok", 1, N, D, H, W, C, K, i3((3, 3, 3)), i3((2, 2, 2))) == 1
+    old = ints((N, C, D, H, W), -3, 3)
+    buf = old.to(DEV).to(BF).contiguous(memory_format=CL)
+    _wf, wb = ops.pack_weight_bf16(w.to(DEV), False)
+    ws = torch.empty(max(1024, query("mvd_conv_fwd_workspace_bytes", N, D * H * W, C)), dtype=torch.uint8, device=DEV)
+    call("mvd_conv3d_dgrad_bf16_acc", _p(dyd), _p(wb), _p(buf), C, N, D, H, W, K, i3((3, 3, 3)), i3((2, 2, 2)), _p(ws), ws.numel(),
+         _stream())
+    assert torch.equal(buf.cpu(), (old + xr.grad).to(BF))
