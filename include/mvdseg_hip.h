@@ -175,6 +175,10 @@ int mvd_conv3d_dgrad_bf16_acc(const uint16_t *dy, const uint16_t *wb, uint16_t *
  * MVD_FWD16Y) = k_fwd16y (16x16x32 tiles; 32 or 64 reduce channels; statistics epilogue and loader prologue), 0 =
  * k_fwd16z (32x32x16 tiles, 32 reduce channels, loader prologue only).  A/B and cross-check switch. */
 int mvd_set_bf16_zmarch_kernel(int which);
+/* which kernel computes the bf16 weight gradient of the plain 3x3x3 stride-1 convs on volumes at least 32 wide
+ * (nnUNetTrainer.py:888-925 backward): 1 (default, MVD_WGRAD16Z) = k_wgrad16z (z-marching column, csrc/conv_bf16w.hip),
+ * 0 = k_wgrad16 (4x8x8 tiles).  A/B and cross-check switch. */
+int mvd_set_bf16_wgrad_kernel(int which);
 /* 1 when mvd_conv3d_fwd_bf16_fused accepts in_scale / in_shift for this shape (a kernel with the loader prologue runs it) */
 int mvd_conv3d_fwd_bf16_prologue_ok(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
                                     const int stride[3]);

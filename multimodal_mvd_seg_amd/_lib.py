@@ -53,6 +53,7 @@ SIGNATURES = {
                                                 _P, c_size_t, _P]),
     "mvd_conv3d_fwd_bf16_stats_tiles": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
     "mvd_set_bf16_zmarch_kernel": (c_int, [c_int]),
+    "mvd_set_bf16_wgrad_kernel": (c_int, [c_int]),
     "mvd_conv3d_dgrad_acc_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
     "mvd_conv3d_dgrad_acc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P]),
     "mvd_conv3d_dgrad_bf16_acc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P, c_size_t, _P]),

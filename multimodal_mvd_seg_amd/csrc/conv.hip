@@ -737,6 +737,15 @@ int mvd_set_bf16_zmarch_kernel(int which) {
     return 0;
 }
 
+int mvd_set_bf16_wgrad_kernel(int which) {
+    if (which != 0 && which != 1) {
+        set_error("set_bf16_wgrad_kernel: 0 = k_wgrad16 (tiled), 1 = k_wgrad16z (z-marching)");
+        return 2;
+    }
+    wgrad16z_enable(which);
+    return 0;
+}
+
 int mvd_conv3d_fwd_bf16_stats_tiles(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
                                     const int stride[3]) {
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || K <= 0 || check_ks(ksize, stride, "conv3d_fwd_bf16_stats_tiles"))

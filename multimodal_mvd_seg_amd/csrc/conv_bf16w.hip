@@ -1,0 +1,439 @@
+// k_wgrad16z (round 3): z-marching weight gradient of the plain 3x3x3 stride-1 convolution in bf16 -- the largest kernel
+// family of the bf16 train step (nnUNetTrainer.py:888-925 backward; the convs of get_network_from_plans.py:41-44 at the
+// 128^3 ... 32^3 stages).
+//
+// Same product as k_wgrad16<7, 10, 4, 1, true> (conv_mfma.hip): dw[tap][c][k] = sum over voxels x[voxel + tap][c] * dy[voxel][k]
+// on v_mfma_f32_32x32x16_bf16 (16 voxels per instruction), operands fetched from channel-contiguous LDS rows with the
+// transposing read ds_read_b64_tr_b16, a wave = two x-triples + one tap of the ninth triple (wave 3's seventh slot
+// multiplies a block of ones: the bias gradient), split-K partials reduced by k_wgrad_reduce_f.  What changes is the data
+// movement.  The tiled kernel stages a 6 x 10 x 10 halo for a 4 x 8 x 8 tile (2.34 x the tile's voxels; PMC round 3: 0.83 GB
+// fetched for 0.54 GB), decodes tile coordinates, reads a per-step offset table and adds an address per transposing read:
+// 6.6 vector instructions per MFMA, bound by the vector issue port (PMC rounds 2 and 3).  Here a workgroup owns a column
+// of 8 x 32 output voxels and marches along z:
+//   * an input plane (10 x 34 halo slots of 64 B) is loaded ONCE and serves the output planes z-1, z, z+1 from a ring of
+//     four LDS images (1.33 x the voxels, the in-plane halo only); dy planes alternate between two images;
+//   * the column is fixed, so every in-plane bound is decided once per column: a lane's buffer-load offset is either its
+//     element's offset or out of range (the descriptor returns zeros), and planes outside the volume / the chunk are
+//     zero-record descriptors -- no bounds logic and no address arithmetic per plane beyond one scalar base;
+//   * the 16 steps of a plane are straight-line code: every LDS read is base register + immediate (row pitch 34 slots,
+//     a step is half an output row); the three fragments of an x-triple come from FOUR reads (slots +0..3, +4..7 for tap
+//     x-1; +2..5, +6..9 for tap x+1: both land in aligned register quads) and four v_alignbit for the odd shift;
+//     12 reads + 8 vector instructions per 7 MFMAs;
+//   * global loads are issued two per step in the middle of a plane and written to LDS a whole plane later (first version:
+//     written ten steps later -- every plane then waited ~1.3 plane times on HBM latency); two barriers per plane (one bare
+//     s_barrier before the writes: the images they overwrite were read by the previous plane; one after them).  One workgroup per CU (143 KB of LDS), so the schedule is explicit: operands of step s+1 are fetched before
+//     the MFMAs of step s.
+// Eligibility (host): 27 taps in raster order, stride 1, pad 1, channels in blocks of 32, W >= 32.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "conv_geom.h"
+
+namespace mvd {
+
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+typedef short s16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8z __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2z __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) s16x4w lds_s16x4w;
+
+constexpr int WZ_TH = 8, WZ_TW = 32;
+constexpr int WZ_SROW = WZ_TW + 2;                  // halo slots per row (= LDS row pitch in slots)
+constexpr int WZ_ROWB = WZ_SROW * 64;               // 2176 B
+constexpr int WZ_PLANE = (WZ_TH + 2) * WZ_ROWB;     // 21760 B per x plane image
+constexpr int WZ_NRING = 4;
+constexpr int WZ_BPLANE = WZ_TH * WZ_TW * 64;       // 16384 B per dy plane image
+constexpr int WZ_BOFF = WZ_NRING * WZ_PLANE;        // 87040
+constexpr int WZ_ONES = WZ_BOFF + 2 * WZ_BPLANE;    // 119808
+// the ones region covers every (base + immediate) the single-tap reads of a plane can form
+constexpr int WZ_ONES_BYTES = (WZ_TH - 1) * WZ_ROWB + (16 + 4 + 11 + 1) * 64;
+constexpr int WZ_LDS = WZ_ONES + WZ_ONES_BYTES;
+constexpr int WZ_APARTS = (WZ_TH + 2) * WZ_SROW * 4;  // 1360 16-byte parts per x plane
+constexpr int WZ_NA = (WZ_APARTS + 255) / 256;        // 6 staging loads per thread
+constexpr int WZ_NB = WZ_TH * WZ_TW * 4 / 256;        // 4
+static_assert(6 + WZ_NA + WZ_NB <= 16, "one staging load per step from step 6");
+static_assert(WZ_LDS <= 160 * 1024, "k_wgrad16z: LDS budget");
+static_assert((WZ_TH - 1) * WZ_ROWB + 16 * 64 + 384 < 65536, "ds_read immediates");
+
+struct WgZTile {
+    int nty, ntx, nzc, zc;   // column tiles, z chunks per column, planes per chunk
+    int nunits, nsplit, nkb;
+};
+
+__device__ inline s16x4w wz_trd(unsigned addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w *)addr);
+}
+
+// Staging loads and their waits are inline asm: the compiler's s_waitcnt pass merges the counter states of the prologue and
+// of both unrolled planes at the loop head and ends up waiting for vmcnt(0) -- for the loads issued five steps earlier -- in
+// front of the dy writes (measured: +0.07 ms).  Issue order is fixed (set S: six x parts, four dy parts; two sets in
+// flight), so the exact counts are known: x parts of the older set done <=> at most 14 loads outstanding, all of it <=> 10.
+__device__ inline void wz_bload(u32x4z &r, unsigned voff, u32x4z rsrc) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc));
+}
+__device__ inline u32x4z wz_rsrc(const char *base, bool ok) {
+    const unsigned long long a = (unsigned long long)(uintptr_t)base;
+    u32x4z r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, ok ? 0x7fffffffu : 0u, 0x00020000u};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]);
+    r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]);
+    return r;
+}
+#define WZ_WAIT6(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]))
+#define WZ_WAIT4(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]))
+
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void k_wgrad16z(const WgradGeom g, const WgZTile tg, const unsigned short *__restrict__ a1,
+                                                     const unsigned short *__restrict__ a2,
+                                                     const unsigned short *__restrict__ b, float *__restrict__ partial,
+                                                     float *__restrict__ pbias) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y / tg.nkb, kb = blockIdx.y % tg.nkb;
+    const int split = blockIdx.x;
+    const int C = g.C1 + g.C2, K = g.K;
+    const int c0 = cb * 32, k0 = kb * 32;
+    const unsigned short *asrc;
+    int Cs, cofs;
+    if (c0 < g.C1) {
+        asrc = a1; Cs = g.C1; cofs = c0;
+    } else {
+        asrc = a2; Cs = g.C2; cofs = c0 - g.C1;
+    }
+    const int D = g.Do, H = g.Ho, W = g.Wo;
+
+    f32x16w acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    // bf16 ones for wave 3's seventh slot (the bias gradient): written once, never overwritten
+    for (int e = tid; e < WZ_ONES_BYTES / 4; e += 256) reinterpret_cast<unsigned *>(lds8 + WZ_ONES)[e] = 0x3f803f80u;
+
+    // transposing-read lane roles (as k_wgrad16): the 16-lane group lane >> 4 takes channels 16 * (group & 1) .. of the voxels
+    // of k-half h; lane 4 q + p of the group supplies the address of voxel row q, channel columns 4 p .. 4 p + 3 (8 bytes)
+    const int q4 = (lane & 15) >> 2;
+    const int colb = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds8 + (unsigned)((8 * h + q4) * 64 + colb);
+    // triples 2 w, 2 w + 1 (dz = T / 3, dy = T % 3), single tap 24 + w of the ninth triple (dz = dy = 2, dx = w)
+    const int T0 = 2 * wave, T1 = 2 * wave + 1;
+    const int dzq0 = T0 / 3, dzq1 = T1 / 3;
+    const unsigned bq0 = lane_base + (unsigned)((T0 % 3) * WZ_ROWB);
+    const unsigned bq1 = lane_base + (unsigned)((T1 % 3) * WZ_ROWB);
+    const bool ones_slot = wave == 3;
+    const unsigned bs_ = ones_slot ? lane_base + (unsigned)WZ_ONES : lane_base + (unsigned)(2 * WZ_ROWB + wave * 64);
+    const unsigned bB = lane_base + (unsigned)WZ_BOFF;
+
+    // staging roles: x plane part idx = u * 256 + tid -> (halo row, halo column, 16-byte part); dy plane part likewise
+    int hrA[WZ_NA], hcA[WZ_NA];
+    unsigned ldsA[WZ_NA];
+#pragma unroll
+    for (int u = 0; u < WZ_NA; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx >> 2, part = idx & 3;
+        const int hr = slot / WZ_SROW, hc = slot - hr * WZ_SROW;
+        hrA[u] = idx < WZ_APARTS ? hr : -100;
+        hcA[u] = hc;
+        ldsA[u] = (unsigned)(hr * WZ_ROWB + hc * 64 + part * 16);
+    }
+
+    for (int unit = split; unit < tg.nunits; unit += tg.nsplit) {
+        unsigned r_ = (unsigned)unit;
+        const int zc_ = (int)(r_ % (unsigned)tg.nzc); r_ /= (unsigned)tg.nzc;
+        const int tx_ = (int)(r_ % (unsigned)tg.ntx); r_ /= (unsigned)tg.ntx;
+        const int ty_ = (int)(r_ % (unsigned)tg.nty);
+        const int n = (int)(r_ / (unsigned)tg.nty);
+        const int y0 = ty_ * WZ_TH, x0 = tx_ * WZ_TW;
+        const int z0 = zc_ * tg.zc;
+        const int nz = min(tg.zc, D - z0);
+        // per-lane element offsets from the column's corner; out of range where the halo voxel lies outside the plane
+        unsigned voA[WZ_NA], voB[WZ_NB];
+#pragma unroll
+        for (int u = 0; u < WZ_NA; u++) {
+            const int gy = y0 - 1 + hrA[u], gx = x0 - 1 + hcA[u];
+            const bool ok = hrA[u] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            voA[u] = ok ? (unsigned)(((hrA[u] * W + hcA[u]) * Cs) * 2 + ((u * 256 + tid) & 3) * 16) : 0x80000000u;
+        }
+#pragma unroll
+        for (int u = 0; u < WZ_NB; u++) {
+            const int idx = u * 256 + tid;
+            const int slot = idx >> 2, r = slot >> 5, c = slot & 31;
+            const bool ok = y0 + r < H && x0 + c < W;
+            voB[u] = ok ? (unsigned)(((r * W + c) * K) * 2 + (idx & 3) * 16) : 0x80000000u;
+        }
+        // corner addresses of plane 0 of this sample (the corner itself may lie outside the volume: only valid lanes load)
+        const long planeA = (long)H * W * Cs * 2, planeB = (long)H * W * K * 2;
+        const char *cornerA = reinterpret_cast<const char *>(asrc) + ((long)n * D * planeA + ((long)(y0 - 1) * W + (x0 - 1)) * Cs * 2 + cofs * 2);
+        const char *cornerB = reinterpret_cast<const char *>(b) + ((long)n * D * planeB + ((long)y0 * W + x0) * K * 2 + k0 * 2);
+        auto rsrcA = [&](int z) {  // x plane z; planes outside the volume are zero-record descriptors (zeros, no traffic)
+            const bool ok = z >= 0 && z < D;
+            return wz_rsrc(cornerA + (ok ? (long)z * planeA : 0), ok);
+        };
+        auto rsrcB = [&](int z, bool want) {
+            const bool ok = want && z >= 0 && z < D;
+            return wz_rsrc(cornerB + (ok ? (long)z * planeB : 0), ok);
+        };
+        // staged planes: set p & 1 is written to LDS by plane p and re-loaded by it for plane p + 2 (two planes in flight:
+        // 76 KB per CU -- with one set the kernel waited on memory half of its time, PMC SQ_WAIT_INST_ANY)
+        u32x4z ra[2][WZ_NA], rb[2][WZ_NB];
+        auto write_A = [&](int slot, const u32x4z (&r)[WZ_NA]) {
+#pragma unroll
+            for (int u = 0; u < WZ_NA; u++)
+                if (u < WZ_NA - 1 || tid < WZ_APARTS - (WZ_NA - 1) * 256)
+                    *reinterpret_cast<u32x4z *>(lds8 + slot * WZ_PLANE + ldsA[u]) = r[u];
+        };
+        auto write_B = [&](int buf, const u32x4z (&r)[WZ_NB]) {
+#pragma unroll
+            for (int u = 0; u < WZ_NB; u++) *reinterpret_cast<u32x4z *>(lds8 + WZ_BOFF + buf * WZ_BPLANE + (u * 256 + tid) * 16) = r[u];
+        };
+        auto load_A = [&](u32x4z (&r)[WZ_NA], const u32x4z d) {
+#pragma unroll
+            for (int u = 0; u < WZ_NA; u++) wz_bload(r[u], voA[u], d);
+        };
+        auto load_B = [&](u32x4z (&r)[WZ_NB], const u32x4z d) {
+#pragma unroll
+            for (int u = 0; u < WZ_NB; u++) wz_bload(r[u], voB[u], d);
+        };
+        // ---- prologue: x planes z0 - 1, z0, z0 + 1 -> ring slots 0, 1, 2; dy plane z0 -> image 0 (all loads in flight
+        // together); sets 0 / 1 = x planes z0 + 2 / z0 + 3 and dy planes z0 + 1 / z0 + 2, written by planes 0 / 1
+        __syncthreads();  // (the previous column's reads are done; no staging load is outstanding)
+        {
+            u32x4z r0[WZ_NA];
+            load_A(r0, rsrcA(z0 - 1));
+            load_A(ra[0], rsrcA(z0));
+            load_A(ra[1], rsrcA(z0 + 1));
+            load_B(rb[0], rsrcB(z0, true));
+            WZ_WAIT6(10, r0);
+            write_A(0, r0);
+            WZ_WAIT6(4, ra[0]);
+            write_A(1, ra[0]);
+            WZ_WAIT6(0, ra[1]);
+            WZ_WAIT4(0, rb[0]);
+            write_A(2, ra[1]);
+            write_B(0, rb[0]);
+            load_A(ra[0], rsrcA(2 <= nz ? z0 + 2 : -1));
+            load_B(rb[0], rsrcB(z0 + 1, 1 < nz));
+            load_A(ra[1], rsrcA(3 <= nz ? z0 + 3 : -1));
+            load_B(rb[1], rsrcB(z0 + 2, 2 < nz));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        // operands: [buf][triple][read], single tap [buf][read], dy [buf][read]
+        s16x4w rt[2][2][4], rs[2][2], rv[2][2];
+        // (read order = the order the next step's MFMAs need them: dy and triple 0 first, the single tap last -- the first
+        // MFMA of a step waits for four reads issued seven gaps earlier, not for the two issued one gap earlier)
+        auto fetch = [&](unsigned aq0, unsigned aq1, unsigned as, unsigned ab, int imm, int immB, int buf) {
+            rv[buf][0] = wz_trd(ab + immB);
+            rv[buf][1] = wz_trd(ab + immB + 256);
+            rt[buf][0][0] = wz_trd(aq0 + imm);
+            rt[buf][0][1] = wz_trd(aq0 + imm + 256);
+            rt[buf][0][2] = wz_trd(aq0 + imm + 128);
+            rt[buf][0][3] = wz_trd(aq0 + imm + 384);
+            rt[buf][1][0] = wz_trd(aq1 + imm);
+            rt[buf][1][1] = wz_trd(aq1 + imm + 256);
+            rt[buf][1][2] = wz_trd(aq1 + imm + 128);
+            rt[buf][1][3] = wz_trd(aq1 + imm + 384);
+            rs[buf][0] = wz_trd(as + imm);
+            rs[buf][1] = wz_trd(as + imm + 256);
+        };
+        // MFMA order of a step: the four fragments that come straight from the reads first, the single tap, then the two
+        // odd-shift fragments -- their eight v_alignbit fill the gaps of the first MFMAs instead of standing in front of them
+        auto mfmas = [&](int buf) {
+            const bf16x8z bfrag = __builtin_bit_cast(bf16x8z, __builtin_shufflevector(rv[buf][0], rv[buf][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            s16x8w f0[2], f1[2], f2[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                f0[q] = __builtin_shufflevector(rt[buf][q][0], rt[buf][q][1], 0, 1, 2, 3, 4, 5, 6, 7);   // voxels x-1 .. x+6
+                f2[q] = __builtin_shufflevector(rt[buf][q][2], rt[buf][q][3], 0, 1, 2, 3, 4, 5, 6, 7);   // x+1 .. x+8
+                f1[q] = __builtin_shufflevector(f0[q], f2[q], 1, 2, 3, 4, 5, 6, 7, 14);                  // x .. x+7
+            }
+            const bf16x8z sfrag = __builtin_bit_cast(bf16x8z, __builtin_shufflevector(rs[buf][0], rs[buf][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f0[0]), bfrag, acc[0], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f2[0]), bfrag, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f0[1]), bfrag, acc[3], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f2[1]), bfrag, acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag, bfrag, acc[6], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f1[0]), bfrag, acc[1], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f1[1]), bfrag, acc[4], 0, 0, 0);
+        };
+        auto ring_of = [&](int p, int dz) { return (unsigned)(((p + dz) & 3) * WZ_PLANE); };
+        unsigned aq0 = bq0 + ring_of(0, dzq0), aq1 = bq1 + ring_of(0, dzq1);
+        unsigned as = ones_slot ? bs_ : bs_ + ring_of(0, 2);
+        unsigned ab = bB;
+        fetch(aq0, aq1, as, ab, 0, 0, 0);
+        auto plane = [&](const int p, auto SETC) {
+            constexpr int SET = decltype(SETC)::value;
+            const int z = z0 + p;
+            // Registers ra / rb[SET] hold x plane z + 2 and dy plane z + 1 (loaded two planes ago): written behind the first
+            // barrier of this plane (the images they replace -- x plane z - 2, dy plane z - 1 -- were read by plane p - 1),
+            // then re-loaded with x plane z + 4 (the halo plane of the chunk's last output plane included) and dy plane z + 3.
+            const u32x4z rA = rsrcA(p + 4 <= nz ? z + 4 : -1);
+            const u32x4z rB = rsrcB(z + 3, p + 3 < nz);
+            const unsigned naq0 = bq0 + ring_of(p + 1, dzq0), naq1 = bq1 + ring_of(p + 1, dzq1);
+            const unsigned nas = ones_slot ? bs_ : bs_ + ring_of(p + 1, 2);
+            const unsigned nab = bB + (unsigned)(((p + 1) & 1) * WZ_BPLANE);
+#pragma unroll
+            for (int st = 0; st < 16; st++) {
+                if (DBG & 1) {
+                } else if (st < 15) {
+                    const int imm = ((st + 1) >> 1) * WZ_ROWB + ((st + 1) & 1) * 16 * 64;
+                    const int immB = (((st + 1) >> 1) * WZ_TW + ((st + 1) & 1) * 16) * 64;
+                    fetch(aq0, aq1, as, ab, imm, immB, (st + 1) & 1);
+                } else {
+                    fetch(naq0, naq1, nas, nab, 0, 0, 0);  // step 0 of the next plane (behind the barrier of step 7)
+                }
+                if (DBG & (2 | 32)) {
+                } else if (st >= 6 && st < 6 + WZ_NA) wz_bload(ra[SET][st - 6], voA[st - 6], rA);
+                else if (st >= 6 + WZ_NA) wz_bload(rb[SET][st - 6 - WZ_NA], voB[st - 6 - WZ_NA], rB);
+                if (!(DBG & 8)) mfmas(st & 1);
+                if (st == 4 && !(DBG & (2 | 64))) {
+                    WZ_WAIT6(14, ra[SET]);  // (20 loads outstanding: this set's ten, then the other set's)
+                    write_A((p + 3) & 3, ra[SET]);
+                }
+                if (st == 5 && !(DBG & (2 | 64))) {
+                    WZ_WAIT4(10, rb[SET]);
+                    write_B((p + 1) & 1, rb[SET]);
+                }
+                // the step as one pipeline: per MFMA gap two transposing reads of the next step's operands, two of this
+                // step's v_alignbit, at most one staging load / LDS write (one wave per SIMD: what is not placed inside
+                // a gap is paid in full -- ablation: reads +0.065, staging +0.063 ms on a 0.15 ms MFMA stream)
+                if (!(DBG & 16)) {
+#pragma unroll
+                    for (int j = 0; j < 7; j++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (j < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (j >= 1 && j < 5) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                                                if ((st == 4 && j < 6) || (st == 5 && j < 4)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st == 3 && !(DBG & 4)) asm volatile("s_barrier" ::: "memory");  // every wave has finished the previous plane's reads
+                if (st == 7 && !(DBG & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            aq0 = naq0; aq1 = naq1; as = nas; ab = nab;
+        };
+        for (int rep = 0; rep < ((DBG & 128) ? 2 : 1); rep++)  // (timing ablation: the plane loop twice = fixed cost + 2 x loop)
+        for (int p = 0; p < nz; p += 2) {
+            plane(p, std::integral_constant<int, 0>());
+            if (p + 1 < nz) plane(p + 1, std::integral_constant<int, 1>());
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last planes' zero-record loads)
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const int t = j < 6 ? 6 * wave + j : 24 + wave;
+        if (t < 27) {
+            float *po = partial + ((size_t)split * 27 + t) * C * K;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                po[(size_t)(c0 + row) * K + k0 + i] = acc[j][r];
+            }
+        }
+    }
+    // every row of the ones-slot accumulator holds the same column sums of dy: row 0 of the c-block-0 workgroups goes out
+    if (ones_slot && pbias != nullptr && cb == 0 && h == 0) pbias[(size_t)split * K + k0 + i] = acc[6][0];
+}
+
+static int &wgrad16z_mode() {
+    static int v = getenv("MVD_WGRAD16Z") ? atoi(getenv("MVD_WGRAD16Z")) : 1;
+    return v;
+}
+void wgrad16z_enable(int on) { wgrad16z_mode() = on; }
+
+// Returns -1 when the problem is not this kernel's (the caller falls through to k_wgrad16), 0 after a launch (the partials
+// [nsplit][27][C][K] and, when pbias_out is set, the bias rows [nsplit][K] are in ws), > 0 on error.
+int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,
+             size_t ws_bytes, bool want_bias, int *nsplit_out, float **pbias_out, hipStream_t s) {
+    if (!wgrad16z_mode()) return -1;
+    const int C = g.C1 + g.C2;
+    if (g.ntaps != 27 || g.T != 27 || g.C1 % 32 != 0 || g.C2 % 32 != 0 || g.K % 32 != 0 || C < 32) return -1;
+    if (g.Di != g.Do || g.Hi != g.Ho || g.Wi != g.Wo || g.Db != g.Do || g.Hb != g.Ho || g.Wb != g.Wo) return -1;
+    for (int a = 0; a < 3; a++)
+        if (g.sa[a] != 1 || g.sb[a] != 1) return -1;
+    for (int t = 0; t < 27; t++)
+        if (g.off[t][0] != t / 9 - 1 || g.off[t][1] != (t / 3) % 3 - 1 || g.off[t][2] != t % 3 - 1 || g.ob[t][0] != 0 ||
+            g.ob[t][1] != 0 || g.ob[t][2] != 0)
+            return -1;
+    if (g.Wo < 32 || g.Ho < 8 || g.Do < 8) return -1;
+    // 32-bit lane offsets inside a plane, 64-bit scalar plane bases
+    if ((long)g.Ho * g.Wo * (g.C1 > g.C2 ? g.C1 : g.C2) * 2 >= (1L << 31) || (long)g.Ho * g.Wo * g.K * 2 >= (1L << 31)) return -1;
+    WgZTile tg;
+    tg.nty = (g.Ho + WZ_TH - 1) / WZ_TH;
+    tg.ntx = (g.Wo + WZ_TW - 1) / WZ_TW;
+    const int ncb = C / 32;
+    tg.nkb = g.K / 32;
+    const long blocks = (long)ncb * tg.nkb;
+    if (blocks > 65535) return -1;
+    const long columns = (long)g.N * tg.nty * tg.ntx;
+    const long per_round = blocks >= 256 ? 1 : 256 / blocks;
+    // z chunks per column: the count that minimises rounds x (planes per chunk + the pipeline fill of a chunk)
+    long best_cost = -1;
+    int best_nzc = 1;
+    for (int nzc = 1; nzc <= 32 && nzc * 8 <= g.Do; nzc++) {
+        const int zc = (g.Do + nzc - 1) / nzc;
+        const int nzc_eff = (g.Do + zc - 1) / zc;
+        const long units = columns * nzc_eff;
+        const long rounds = (units + per_round - 1) / per_round;
+        const long cost = rounds * (zc + 4);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_nzc = nzc_eff;
+        }
+    }
+    tg.zc = (g.Do + best_nzc - 1) / best_nzc;
+    tg.nzc = (g.Do + tg.zc - 1) / tg.zc;
+    const long units = columns * tg.nzc;
+    if (units > (1L << 30)) return -1;
+    tg.nunits = (int)units;
+    const long rounds = (units + per_round - 1) / per_round;
+    tg.nsplit = (int)((units + rounds - 1) / rounds);
+    const size_t need = (size_t)tg.nsplit * 27 * C * g.K * sizeof(float);
+    const size_t need_b = want_bias ? (size_t)tg.nsplit * g.K * sizeof(float) : 0;
+    if (need + need_b > ws_bytes) return -1;
+    float *partial = reinterpret_cast<float *>(ws);
+    float *pbias = want_bias ? partial + need / sizeof(float) : nullptr;
+    typedef void (*kfn_t)(const WgradGeom, const WgZTile, const unsigned short *, const unsigned short *, const unsigned short *,
+                          float *, float *);
+    kfn_t kfn = k_wgrad16z<0>;
+#ifdef MVD_WG16Z_ABLATE
+    static const int dbg = getenv("MVD_WG16Z_DBG") ? atoi(getenv("MVD_WG16Z_DBG")) : 0;  // timing ablation only: results are wrong
+    if (dbg == 1) kfn = k_wgrad16z<1>;
+    if (dbg == 2) kfn = k_wgrad16z<2>;
+    if (dbg == 4) kfn = k_wgrad16z<4>;
+    if (dbg == 8) kfn = k_wgrad16z<8>;
+    if (dbg == 3) kfn = k_wgrad16z<3>;
+    if (dbg == 7) kfn = k_wgrad16z<7>;
+    if (dbg == 6) kfn = k_wgrad16z<6>;
+    if (dbg == 16) kfn = k_wgrad16z<16>;
+    if (dbg == 32) kfn = k_wgrad16z<32>;
+    if (dbg == 128) kfn = k_wgrad16z<128>;
+    if (dbg == 130) kfn = k_wgrad16z<130>;
+    if (dbg == 131) kfn = k_wgrad16z<131>;
+    if (dbg == 129) kfn = k_wgrad16z<129>;
+    if (dbg == 64) kfn = k_wgrad16z<64>;
+#endif
+    static PerDeviceFlag cfgd;
+    if (!cfgd()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, WZ_LDS) != hipSuccess) {
+            set_error("conv wgrad (bf16 z-marching): cannot raise the dynamic LDS limit");
+            return 1;
+        }
+        cfgd() = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(tg.nsplit, (unsigned)blocks), dim3(256), WZ_LDS, s, g, tg, a1, a2, b, partial, pbias);
+    if (check_launch("conv wgrad (bf16 z-marching)")) return 1;
+    *nsplit_out = tg.nsplit;
+    *pbias_out = pbias;
+    return 0;
+}
+
+}  // namespace mvd

@@ -86,6 +86,11 @@ int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, c
 // bf16 twin (conv_bf16.hip): all eight parity classes of a 3x3x3 stride-2 conv's input gradient from one staged dy tile
 int dgrad16s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const unsigned short *dy, const unsigned short *wb,
              unsigned short *dx, hipStream_t s, int accumulate = 0);
+// bf16 z-marching weight gradient of the plain 3x3x3 stride-1 conv (conv_bf16w.hip): -1 = not this kernel's problem, 0 = the
+// partials [nsplit][27][C][K] (and, if asked, bias rows [nsplit][K] at *pbias_out) are in ws
+int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,
+             size_t ws_bytes, bool want_bias, int *nsplit_out, float **pbias_out, hipStream_t s);
+void wgrad16z_enable(int on);
 int pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf, float *const *ub,
                        const int *K, const int *C, const int *T, const int *transposed, hipStream_t s);
 int wino_mode();                          // MVD_WINO: 0 off, 1 F(2,3) along W, 2 F(2x2,3x3) (default)

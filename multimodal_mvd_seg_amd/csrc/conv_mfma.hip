@@ -2760,6 +2760,26 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     if (((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)b) & 15) return -1;
     if (bf16_in && (g.C1 % 32 != 0 || g.C2 % 32 != 0 || g.K % 32 != 0)) return -1;
     const int C = g.C1 + g.C2;
+    if (bf16_in) {  // plain 3x3x3 stride 1 on volumes at least 32 wide: the z-marching kernel (conv_bf16w.hip)
+        int nsplit_z = 0;
+        float *pbias_z = nullptr;
+        const int rz = wgrad16z(g, reinterpret_cast<const unsigned short *>(a1), reinterpret_cast<const unsigned short *>(a2),
+                                reinterpret_cast<const unsigned short *>(b), ws, ws_bytes, dbias && dbias_done, &nsplit_z, &pbias_z, s);
+        if (rz > 0) return rz;
+        if (rz == 0) {
+            float *partial_z = reinterpret_cast<float *>(ws);
+            const int wblocks = (int)cdiv((long)27 * C * g.K, 64);
+            if (pbias_z) {
+                hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks + cdiv(g.K, 64)), dim3(256), 0, s, g, partial_z, dw, nsplit_z, pbias_z,
+                                   dbias, nsplit_z, wblocks);
+                *dbias_done = 1;
+            } else {
+                hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks), dim3(256), 0, s, g, partial_z, dw, nsplit_z, (const float *)nullptr,
+                                   (float *)nullptr, 0, 0);
+            }
+            return check_launch("conv wgrad reduce (bf16 z-marching)");
+        }
+    }
     WgTile tg;
     memset(&tg, 0, sizeof(tg));
     tg.dbg = getenv("MVD_CONV_DBG") ? atoi(getenv("MVD_CONV_DBG")) : 0;

@@ -378,3 +378,59 @@ def test_fused_stride2_input_gradient_bf16_exact_integer_data_and_accumulate_for
     call("mvd_conv3d_dgrad_bf16_acc", _p(dyd), _p(wb), _p(buf), C, N, D, H, W, K, i3((3, 3, 3)), i3((2, 2, 2)), _p(ws), ws.numel(),
          _stream())
     assert torch.equal(buf.cpu(), (old + xr.grad).to(BF))
+
+
+def _set_wgrad_kernel(which):
+    from multimodal_mvd_seg_amd._lib import call
+    call("mvd_set_bf16_wgrad_kernel", which)
+
+
+@pytest.mark.parametrize("C1,C2,K,N,D,H,W", [(32, 0, 32, 2, 52, 60, 44), (32, 0, 32, 1, 33, 70, 97), (32, 0, 32, 1, 128, 64, 64),
+                                              (32, 32, 32, 1, 40, 44, 70), (32, 32, 32, 2, 64, 64, 64), (64, 0, 64, 2, 64, 64, 64),
+                                              (64, 64, 64, 1, 40, 41, 66), (128, 0, 128, 2, 32, 32, 32), (128, 128, 128, 1, 32, 32, 32),
+                                              (32, 0, 64, 1, 9, 8, 32), (32, 0, 32, 1, 8, 13, 33)])
+def test_wgrad16z_exact_integer_data_weight_and_bias_gradient(C1, C2, K, N, D, H, W):
+    """k_wgrad16z (z-marching bf16 weight gradient of the plain 3x3x3 stride-1 conv) on small-integer data: every product and
+    fp32 partial sum is an exact integer, so dw and db must equal torch's exact fp32 result bit for bit -- one and two
+    source tensors (UNetDecoder.py:107), 32 ... 128 channel blocks, ragged volumes (rows / columns / planes outside the
+    volume come back as zeros from the buffer descriptors; chunked z ranges with their halo planes), several columns per
+    workgroup.  The tiled kernel k_wgrad16 on the same data must agree."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(D * 5 + W + C2)
+    ints = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=g).float()
+    C = C1 + C2
+    x, w, b = ints((N, C, D, H, W), -2, 2), ints((K, C, 3, 3, 3), -1, 1), ints((K,), -1, 1)
+    gy = ints((N, K, D, H, W), -1, 1)
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    F.conv3d(x, wr, br, 1, 1).backward(gy)
+    res = []
+    for which in (1, 0):
+        _set_wgrad_kernel(which)
+        try:
+            g1 = x[:, :C1].to(DEV).to(BF).contiguous(memory_format=CL).requires_grad_()
+            g2 = x[:, C1:].to(DEV).to(BF).contiguous(memory_format=CL).requires_grad_() if C2 else None
+            gw, gb = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+            y = ops.Conv3dFn.apply(g1, g2, gw, gb, (1, 1, 1))
+            y.backward(gy.to(DEV).to(BF).contiguous(memory_format=CL))
+        finally:
+            _set_wgrad_kernel(1)
+        assert torch.equal(gw.grad.cpu(), wr.grad), f"dw (kernel {which}): {int((gw.grad.cpu() != wr.grad).sum())} of {wr.grad.numel()} differ"
+        assert torch.equal(gb.grad.cpu(), br.grad), f"db (kernel {which})"
+        res.append(gw.grad)
+    assert torch.equal(res[0], res[1])
+
+
+def test_wgrad16z_random_data_against_fp64():
+    from multimodal_mvd_seg_amd import ops
+    N, C, K, D, H, W = 1, 32, 32, 48, 40, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, D, H, W, generator=g).to(BF)
+    w = torch.randn(K, C, 3, 3, 3, generator=g) / np.sqrt(27 * C)
+    gy = torch.randn(N, K, D, H, W, generator=g).to(BF)
+    wr = w.double().requires_grad_()
+    F.conv3d(x.double(), wr, None, 1, 1).backward(gy.double())
+    gx = x.to(DEV).contiguous(memory_format=CL).requires_grad_()
+    gw = w.to(DEV).requires_grad_()
+    ops.Conv3dFn.apply(gx, None, gw, None, (1, 1, 1)).backward(gy.to(DEV).contiguous(memory_format=CL))
+    err = (gw.grad.cpu().double() - wr.grad).abs().max()
+    assert float(err) <= 1e-5 * float(wr.grad.abs().max()) + 1e-3, float(err)  # fp32 accumulation of exact bf16 products
