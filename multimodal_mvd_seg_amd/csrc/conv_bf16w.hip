@@ -53,9 +53,6 @@ constexpr int WZ_ONES = WZ_BOFF + 2 * WZ_BPLANE;    // 119808
 constexpr int WZ_ONES_BYTES = (WZ_TH - 1) * WZ_ROWB + (16 + 4 + 11 + 1) * 64;
 constexpr int WZ_LDS = WZ_ONES + WZ_ONES_BYTES;
 constexpr int WZ_APARTS = (WZ_TH + 2) * WZ_SROW * 4;  // 1360 16-byte parts per x plane
-constexpr int WZ_NA = (WZ_APARTS + 255) / 256;        // 6 staging loads per thread
-constexpr int WZ_NB = WZ_TH * WZ_TW * 4 / 256;        // 4
-static_assert(6 + WZ_NA + WZ_NB <= 16, "one staging load per step from step 6");
 static_assert(WZ_LDS <= 160 * 1024, "k_wgrad16z: LDS budget");
 static_assert((WZ_TH - 1) * WZ_ROWB + 16 * 64 + 384 < 65536, "ds_read immediates");
 
@@ -69,9 +66,9 @@ __device__ inline s16x4w wz_trd(unsigned addr) {
 }
 
 // Staging loads and their waits are inline asm: the compiler's s_waitcnt pass merges the counter states of the prologue and
-// of both unrolled planes at the loop head and ends up waiting for vmcnt(0) -- for the loads issued five steps earlier -- in
-// front of the dy writes (measured: +0.07 ms).  Issue order is fixed (set S: six x parts, four dy parts; two sets in
-// flight), so the exact counts are known: x parts of the older set done <=> at most 14 loads outstanding, all of it <=> 10.
+// of both unrolled planes at the loop head and ends up waiting for vmcnt(0) -- for the loads issued a few steps earlier -- in
+// front of the dy writes.  Issue order is fixed (set S: NA x parts, then NB dy parts; two sets in flight), so the exact
+// counts are known: x parts of the older set done <=> at most 2 (NA + NB) - NA loads outstanding, all of it <=> NA + NB.
 __device__ inline void wz_bload(u32x4z &r, unsigned voff, u32x4z rsrc) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc));
 }
@@ -83,17 +80,39 @@ __device__ inline u32x4z wz_rsrc(const char *base, bool ok) {
     r[2] = __builtin_amdgcn_readfirstlane(r[2]);
     return r;
 }
-#define WZ_WAIT6(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]))
-#define WZ_WAIT4(N, r) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]))
+template <int N, int CNT>
+__device__ inline void wz_wait(u32x4z (&r)[CNT]) {  // s_waitcnt vmcnt(N); the staged registers are only valid behind it
+    static_assert(CNT == 2 || CNT == 3 || CNT == 4 || CNT == 6, "staging set sizes");
+    if constexpr (CNT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N));
+    if constexpr (CNT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) : "n"(N));
+    if constexpr (CNT == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
+    if constexpr (CNT == 6)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(N));
+}
 
-template <int DBG>
-__global__ __launch_bounds__(256, 1) void k_wgrad16z(const WgradGeom g, const WgZTile tg, const unsigned short *__restrict__ a1,
-                                                     const unsigned short *__restrict__ a2,
-                                                     const unsigned short *__restrict__ b, float *__restrict__ partial,
-                                                     float *__restrict__ pbias) {
+// NG = wave groups of the workgroup (4 waves each).  NG = 2: eight waves, two per SIMD -- group g takes the output rows
+// 4 g .. 4 g + 3 of every plane (8 of its 16 steps) with its own accumulators, which are added through LDS at the end.
+// Ablation (round 3, 32 -> 32 @128^3, kernel time under rocprofv3 with GRBM_GUI_ACTIVE): full kernel 193 us = 340 k cycles per
+// XCD at 1.76 GHz; without the staging loads / LDS writes 146 us = 295 k at 2.02 GHz; MFMAs + shifts only 135 us = 291 k at
+// 2.16 GHz; everything but the MFMAs 97 us at 2.51 GHz -- MFMA stream plus HBM stream run into the power limit, so the
+// parts "add up" in time although they overlap in cycles.  NG = 2 hides the operand reads (plane loop without staging
+// 0.142 vs 0.161 ms) but not that.
+template <int DBG, int NG>
+__global__ __launch_bounds__(256 * NG, 1) void k_wgrad16z(const WgradGeom g, const WgZTile tg, const unsigned short *__restrict__ a1,
+                                                          const unsigned short *__restrict__ a2,
+                                                          const unsigned short *__restrict__ b, float *__restrict__ partial,
+                                                          float *__restrict__ pbias) {
+    constexpr int NT = 256 * NG;                     // threads
+    constexpr int NA = (WZ_APARTS + NT - 1) / NT;    // staging loads per thread: x plane (6 / 3)
+    constexpr int NB = WZ_TH * WZ_TW * 4 / NT;       // dy plane (4 / 2)
+    constexpr int SP = 16 / NG;                      // steps per plane and wave
+    constexpr int ST_BAR1 = NG == 1 ? 3 : 0, ST_WA = ST_BAR1 + 1, ST_WB = ST_BAR1 + 2, ST_BAR2 = NG == 1 ? 7 : 3;
+    constexpr int ST_LD0 = NG == 1 ? 6 : 3;          // one staging load per step from here
+    static_assert(ST_LD0 + NA + NB <= SP && ST_WB < ST_LD0 + (NG == 1 ? 1 : 1), "staging schedule");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;
     const int i = lane & 31, h = lane >> 5;
     const int cb = blockIdx.y / tg.nkb, kb = blockIdx.y % tg.nkb;
     const int split = blockIdx.x;
@@ -115,33 +134,34 @@ __global__ __launch_bounds__(256, 1) void k_wgrad16z(const WgradGeom g, const Wg
         for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 
     // bf16 ones for wave 3's seventh slot (the bias gradient): written once, never overwritten
-    for (int e = tid; e < WZ_ONES_BYTES / 4; e += 256) reinterpret_cast<unsigned *>(lds8 + WZ_ONES)[e] = 0x3f803f80u;
+    for (int e = tid; e < WZ_ONES_BYTES / 4; e += NT) reinterpret_cast<unsigned *>(lds8 + WZ_ONES)[e] = 0x3f803f80u;
 
     // transposing-read lane roles (as k_wgrad16): the 16-lane group lane >> 4 takes channels 16 * (group & 1) .. of the voxels
     // of k-half h; lane 4 q + p of the group supplies the address of voxel row q, channel columns 4 p .. 4 p + 3 (8 bytes)
     const int q4 = (lane & 15) >> 2;
     const int colb = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
     const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds8 + (unsigned)((8 * h + q4) * 64 + colb);
+    // the wave group's first output row
+    const unsigned growA = (unsigned)(grp * (WZ_TH / NG) * WZ_ROWB), growB = (unsigned)(grp * (WZ_TH / NG) * WZ_TW * 64);
     // triples 2 w, 2 w + 1 (dz = T / 3, dy = T % 3), single tap 24 + w of the ninth triple (dz = dy = 2, dx = w)
     const int T0 = 2 * wave, T1 = 2 * wave + 1;
     const int dzq0 = T0 / 3, dzq1 = T1 / 3;
-    const unsigned bq0 = lane_base + (unsigned)((T0 % 3) * WZ_ROWB);
-    const unsigned bq1 = lane_base + (unsigned)((T1 % 3) * WZ_ROWB);
+    const unsigned bq0 = lane_base + growA + (unsigned)((T0 % 3) * WZ_ROWB);
+    const unsigned bq1 = lane_base + growA + (unsigned)((T1 % 3) * WZ_ROWB);
     const bool ones_slot = wave == 3;
-    const unsigned bs_ = ones_slot ? lane_base + (unsigned)WZ_ONES : lane_base + (unsigned)(2 * WZ_ROWB + wave * 64);
-    const unsigned bB = lane_base + (unsigned)WZ_BOFF;
+    const unsigned bs_ = ones_slot ? lane_base + (unsigned)WZ_ONES : lane_base + growA + (unsigned)(2 * WZ_ROWB + wave * 64);
+    const unsigned bB = lane_base + growB + (unsigned)WZ_BOFF;
 
-    // staging roles: x plane part idx = u * 256 + tid -> (halo row, halo column, 16-byte part); dy plane part likewise
-    int hrA[WZ_NA], hcA[WZ_NA];
-    unsigned ldsA[WZ_NA];
+    // staging roles: x plane part idx = u * NT + tid -> (halo row, halo column, 16-byte part), LDS image linear in idx;
+    // dy plane part likewise
+    int hrA[NA], hcA[NA];
 #pragma unroll
-    for (int u = 0; u < WZ_NA; u++) {
-        const int idx = u * 256 + tid;
-        const int slot = idx >> 2, part = idx & 3;
+    for (int u = 0; u < NA; u++) {
+        const int idx = u * NT + tid;
+        const int slot = idx >> 2;
         const int hr = slot / WZ_SROW, hc = slot - hr * WZ_SROW;
         hrA[u] = idx < WZ_APARTS ? hr : -100;
         hcA[u] = hc;
-        ldsA[u] = (unsigned)(hr * WZ_ROWB + hc * 64 + part * 16);
     }
 
     for (int unit = split; unit < tg.nunits; unit += tg.nsplit) {
@@ -154,16 +174,16 @@ __global__ __launch_bounds__(256, 1) void k_wgrad16z(const WgradGeom g, const Wg
         const int z0 = zc_ * tg.zc;
         const int nz = min(tg.zc, D - z0);
         // per-lane element offsets from the column's corner; out of range where the halo voxel lies outside the plane
-        unsigned voA[WZ_NA], voB[WZ_NB];
+        unsigned voA[NA], voB[NB];
 #pragma unroll
-        for (int u = 0; u < WZ_NA; u++) {
+        for (int u = 0; u < NA; u++) {
             const int gy = y0 - 1 + hrA[u], gx = x0 - 1 + hcA[u];
             const bool ok = hrA[u] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            voA[u] = ok ? (unsigned)(((hrA[u] * W + hcA[u]) * Cs) * 2 + ((u * 256 + tid) & 3) * 16) : 0x80000000u;
+            voA[u] = ok ? (unsigned)(((hrA[u] * W + hcA[u]) * Cs) * 2 + ((u * NT + tid) & 3) * 16) : 0x80000000u;
         }
 #pragma unroll
-        for (int u = 0; u < WZ_NB; u++) {
-            const int idx = u * 256 + tid;
+        for (int u = 0; u < NB; u++) {
+            const int idx = u * NT + tid;
             const int slot = idx >> 2, r = slot >> 5, c = slot & 31;
             const bool ok = y0 + r < H && x0 + c < W;
             voB[u] = ok ? (unsigned)(((r * W + c) * K) * 2 + (idx & 3) * 16) : 0x80000000u;
@@ -180,42 +200,41 @@ __global__ __launch_bounds__(256, 1) void k_wgrad16z(const WgradGeom g, const Wg
             const bool ok = want && z >= 0 && z < D;
             return wz_rsrc(cornerB + (ok ? (long)z * planeB : 0), ok);
         };
-        // staged planes: set p & 1 is written to LDS by plane p and re-loaded by it for plane p + 2 (two planes in flight:
-        // 76 KB per CU -- with one set the kernel waited on memory half of its time, PMC SQ_WAIT_INST_ANY)
-        u32x4z ra[2][WZ_NA], rb[2][WZ_NB];
-        auto write_A = [&](int slot, const u32x4z (&r)[WZ_NA]) {
+        // staged planes: set p & 1 is written to LDS by plane p and re-loaded by it for plane p + 2 (two planes in flight)
+        u32x4z ra[2][NA], rb[2][NB];
+        auto write_A = [&](int slot, const u32x4z (&r)[NA]) {
 #pragma unroll
-            for (int u = 0; u < WZ_NA; u++)
-                if (u < WZ_NA - 1 || tid < WZ_APARTS - (WZ_NA - 1) * 256)
-                    *reinterpret_cast<u32x4z *>(lds8 + slot * WZ_PLANE + ldsA[u]) = r[u];
+            for (int u = 0; u < NA; u++)
+                if (u < NA - 1 || tid < WZ_APARTS - (NA - 1) * NT)
+                    *reinterpret_cast<u32x4z *>(lds8 + slot * WZ_PLANE + (u * NT + tid) * 16) = r[u];
         };
-        auto write_B = [&](int buf, const u32x4z (&r)[WZ_NB]) {
+        auto write_B = [&](int buf, const u32x4z (&r)[NB]) {
 #pragma unroll
-            for (int u = 0; u < WZ_NB; u++) *reinterpret_cast<u32x4z *>(lds8 + WZ_BOFF + buf * WZ_BPLANE + (u * 256 + tid) * 16) = r[u];
+            for (int u = 0; u < NB; u++) *reinterpret_cast<u32x4z *>(lds8 + WZ_BOFF + buf * WZ_BPLANE + (u * NT + tid) * 16) = r[u];
         };
-        auto load_A = [&](u32x4z (&r)[WZ_NA], const u32x4z d) {
+        auto load_A = [&](u32x4z (&r)[NA], const u32x4z d) {
 #pragma unroll
-            for (int u = 0; u < WZ_NA; u++) wz_bload(r[u], voA[u], d);
+            for (int u = 0; u < NA; u++) wz_bload(r[u], voA[u], d);
         };
-        auto load_B = [&](u32x4z (&r)[WZ_NB], const u32x4z d) {
+        auto load_B = [&](u32x4z (&r)[NB], const u32x4z d) {
 #pragma unroll
-            for (int u = 0; u < WZ_NB; u++) wz_bload(r[u], voB[u], d);
+            for (int u = 0; u < NB; u++) wz_bload(r[u], voB[u], d);
         };
         // ---- prologue: x planes z0 - 1, z0, z0 + 1 -> ring slots 0, 1, 2; dy plane z0 -> image 0 (all loads in flight
         // together); sets 0 / 1 = x planes z0 + 2 / z0 + 3 and dy planes z0 + 1 / z0 + 2, written by planes 0 / 1
         __syncthreads();  // (the previous column's reads are done; no staging load is outstanding)
         {
-            u32x4z r0[WZ_NA];
+            u32x4z r0[NA];
             load_A(r0, rsrcA(z0 - 1));
             load_A(ra[0], rsrcA(z0));
             load_A(ra[1], rsrcA(z0 + 1));
             load_B(rb[0], rsrcB(z0, true));
-            WZ_WAIT6(10, r0);
+            wz_wait<2 * NA + NB>(r0);
             write_A(0, r0);
-            WZ_WAIT6(4, ra[0]);
+            wz_wait<NA + NB>(ra[0]);
             write_A(1, ra[0]);
-            WZ_WAIT6(0, ra[1]);
-            WZ_WAIT4(0, rb[0]);
+            wz_wait<0>(ra[1]);
+            wz_wait<0>(rb[0]);
             write_A(2, ra[1]);
             write_B(0, rb[0]);
             load_A(ra[0], rsrcA(2 <= nz ? z0 + 2 : -1));
@@ -280,42 +299,41 @@ __global__ __launch_bounds__(256, 1) void k_wgrad16z(const WgradGeom g, const Wg
             const unsigned nas = ones_slot ? bs_ : bs_ + ring_of(p + 1, 2);
             const unsigned nab = bB + (unsigned)(((p + 1) & 1) * WZ_BPLANE);
 #pragma unroll
-            for (int st = 0; st < 16; st++) {
+            for (int st = 0; st < SP; st++) {
                 if (DBG & 1) {
-                } else if (st < 15) {
+                } else if (st < SP - 1) {
                     const int imm = ((st + 1) >> 1) * WZ_ROWB + ((st + 1) & 1) * 16 * 64;
                     const int immB = (((st + 1) >> 1) * WZ_TW + ((st + 1) & 1) * 16) * 64;
                     fetch(aq0, aq1, as, ab, imm, immB, (st + 1) & 1);
                 } else {
-                    fetch(naq0, naq1, nas, nab, 0, 0, 0);  // step 0 of the next plane (behind the barrier of step 7)
+                    fetch(naq0, naq1, nas, nab, 0, 0, 0);  // step 0 of the next plane (behind this plane's second barrier)
                 }
                 if (DBG & (2 | 32)) {
-                } else if (st >= 6 && st < 6 + WZ_NA) wz_bload(ra[SET][st - 6], voA[st - 6], rA);
-                else if (st >= 6 + WZ_NA) wz_bload(rb[SET][st - 6 - WZ_NA], voB[st - 6 - WZ_NA], rB);
+                } else if (st >= ST_LD0 && st < ST_LD0 + NA) wz_bload(ra[SET][st - ST_LD0], voA[st - ST_LD0], rA);
+                else if (st >= ST_LD0 + NA && st < ST_LD0 + NA + NB) wz_bload(rb[SET][st - ST_LD0 - NA], voB[st - ST_LD0 - NA], rB);
                 if (!(DBG & 8)) mfmas(st & 1);
-                if (st == 4 && !(DBG & (2 | 64))) {
-                    WZ_WAIT6(14, ra[SET]);  // (20 loads outstanding: this set's ten, then the other set's)
+                if (st == ST_WA && !(DBG & (2 | 64))) {
+                    wz_wait<2 * (NA + NB) - NA>(ra[SET]);  // (this set's loads are the older half of those outstanding)
                     write_A((p + 3) & 3, ra[SET]);
                 }
-                if (st == 5 && !(DBG & (2 | 64))) {
-                    WZ_WAIT4(10, rb[SET]);
+                if (st == ST_WB && !(DBG & (2 | 64))) {
+                    wz_wait<NA + NB>(rb[SET]);
                     write_B((p + 1) & 1, rb[SET]);
                 }
-                // the step as one pipeline: per MFMA gap two transposing reads of the next step's operands, two of this
-                // step's v_alignbit, at most one staging load / LDS write (one wave per SIMD: what is not placed inside
-                // a gap is paid in full -- ablation: reads +0.065, staging +0.063 ms on a 0.15 ms MFMA stream)
+                // the step as one pipeline: per MFMA gap two transposing reads of the next step's operands and two of this
+                // step's v_alignbit (NG = 1: what is not placed inside a gap is paid in full)
                 if (!(DBG & 16)) {
 #pragma unroll
                     for (int j = 0; j < 7; j++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (j < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                         if (j >= 1 && j < 5) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                                                if ((st == 4 && j < 6) || (st == 5 && j < 4)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        if ((st == ST_WA && j < NA) || (st == ST_WB && j < NB)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (st == 3 && !(DBG & 4)) asm volatile("s_barrier" ::: "memory");  // every wave has finished the previous plane's reads
-                if (st == 7 && !(DBG & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (st == ST_BAR1 && !(DBG & 4)) asm volatile("s_barrier" ::: "memory");  // every wave has finished the previous plane's reads
+                if (st == ST_BAR2 && !(DBG & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
             aq0 = naq0; aq1 = naq1; as = nas; ab = nab;
@@ -326,6 +344,23 @@ __global__ __launch_bounds__(256, 1) void k_wgrad16z(const WgradGeom g, const Wg
             if (p + 1 < nz) plane(p + 1, std::integral_constant<int, 1>());
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last planes' zero-record loads)
+    }
+    if constexpr (NG == 2) {  // group 1's sums join group 0's through LDS ([register][thread]: conflict-free)
+        __syncthreads();
+        float *lf = reinterpret_cast<float *>(lds8);
+        static_assert(7 * 16 * 256 * 4 <= WZ_LDS, "accumulator exchange fits the LDS allocation");
+        if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) lf[(j * 16 + r) * 256 + (tid & 255)] = acc[j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[j][r] += lf[(j * 16 + r) * 256 + tid];
     }
 #pragma unroll
     for (int j = 0; j < 7; j++) {
@@ -403,23 +438,16 @@ int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short 
     float *pbias = want_bias ? partial + need / sizeof(float) : nullptr;
     typedef void (*kfn_t)(const WgradGeom, const WgZTile, const unsigned short *, const unsigned short *, const unsigned short *,
                           float *, float *);
-    kfn_t kfn = k_wgrad16z<0>;
+    // wave groups: 1 (default) = four waves, 2 = eight.  Measured equal inside the step (11.27-11.41 vs 11.39-11.48 ms): with
+    // the staging traffic on, the kernel runs against the power limit (1.76 GHz; 2.16 GHz for the MFMA stream alone), where
+    // the cycles the second wave per SIMD saves (340 k -> 300 k per XCD without staging) do not turn into time
+    static const int ng = getenv("MVD_WGRAD16Z_NG") ? (atoi(getenv("MVD_WGRAD16Z_NG")) == 2 ? 2 : 1) : 1;
+    kfn_t kfn = ng == 2 ? k_wgrad16z<0, 2> : k_wgrad16z<0, 1>;
 #ifdef MVD_WG16Z_ABLATE
     static const int dbg = getenv("MVD_WG16Z_DBG") ? atoi(getenv("MVD_WG16Z_DBG")) : 0;  // timing ablation only: results are wrong
-    if (dbg == 1) kfn = k_wgrad16z<1>;
-    if (dbg == 2) kfn = k_wgrad16z<2>;
-    if (dbg == 4) kfn = k_wgrad16z<4>;
-    if (dbg == 8) kfn = k_wgrad16z<8>;
-    if (dbg == 3) kfn = k_wgrad16z<3>;
-    if (dbg == 7) kfn = k_wgrad16z<7>;
-    if (dbg == 6) kfn = k_wgrad16z<6>;
-    if (dbg == 16) kfn = k_wgrad16z<16>;
-    if (dbg == 32) kfn = k_wgrad16z<32>;
-    if (dbg == 128) kfn = k_wgrad16z<128>;
-    if (dbg == 130) kfn = k_wgrad16z<130>;
-    if (dbg == 131) kfn = k_wgrad16z<131>;
-    if (dbg == 129) kfn = k_wgrad16z<129>;
-    if (dbg == 64) kfn = k_wgrad16z<64>;
+#define WZ_DBG(V) if (dbg == V) kfn = ng == 2 ? k_wgrad16z<V, 2> : k_wgrad16z<V, 1>;
+    WZ_DBG(1) WZ_DBG(2) WZ_DBG(3) WZ_DBG(4) WZ_DBG(8) WZ_DBG(16) WZ_DBG(32) WZ_DBG(64) WZ_DBG(128) WZ_DBG(129) WZ_DBG(130) WZ_DBG(131) WZ_DBG(160) WZ_DBG(192) WZ_DBG(136) WZ_DBG(132)
+#undef WZ_DBG
 #endif
     static PerDeviceFlag cfgd;
     if (!cfgd()) {
@@ -429,7 +457,7 @@ int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short 
         }
         cfgd() = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(tg.nsplit, (unsigned)blocks), dim3(256), WZ_LDS, s, g, tg, a1, a2, b, partial, pbias);
+    hipLaunchKernelGGL(kfn, dim3(tg.nsplit, (unsigned)blocks), dim3(256 * ng), WZ_LDS, s, g, tg, a1, a2, b, partial, pbias);
     if (check_launch("conv wgrad (bf16 z-marching)")) return 1;
     *nsplit_out = tg.nsplit;
     *pbias_out = pbias;
