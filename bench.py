@@ -150,7 +150,7 @@ def bf16_block_roofline(torch, dev, patch):
     with torch.no_grad():
         blk2.conv.weight.normal_(0, 0.05)
 
-    def block():      # the block as the TRAIN STEP runs it: conv (+ statistics epilogue) -> finalize -> apply pass
+    def block():      # the un-fused form: conv (+ statistics epilogue) -> finalize -> apply pass
         with torch.no_grad():
             blk.norm_act(blk.conv_only(x))
 
@@ -158,39 +158,49 @@ def bf16_block_roofline(torch, dev, patch):
         y_raw = blk.conv_only(x)
     fused_ok = ops.fused_norm_conv_ok(y_raw, blk2.conv.weight, blk2.stride)
 
-    def block_fused():  # the block as the INFERENCE forward runs it: the previous block's finalize + this conv with the
+    def block_fused():  # the fused form (inference; training where k_wgrad16z serves the shape): finalize + this conv with the
         with torch.no_grad():  # InstanceNorm-apply + LeakyReLU in its loader and the statistics in its epilogue
             blk2.forward_from_raw(blk, y_raw)
     ms = time_kernel(conv, 10, torch)
-    bms = time_graphed(block, 10, torch)
+    ums = time_graphed(block, 10, torch)
     fms = time_graphed(block_fused, 10, torch) if fused_ok else None
+    # which form the TRAIN step runs for this block (a 32 -> 32 conv fed by a 32-channel conv: stage 0 / the top decoder stage):
+    # the fused one when the weight-gradient kernel has the loader prologue too (network.StackedConvBlocks._can_fuse, "auto")
+    with torch.enable_grad():
+        train_fused = fms is not None and network.StackedConvBlocks._can_fuse(blk, blk2, x)
+    bms = fms if train_fused else ums
     V = float(N * D * H * W)
     alg_bytes = (C + K) * V * 2.0
     flops = 2.0 * 27 * C * K * V
     gbs = alg_bytes / (bms * 1e-3) / 1e9
     cgbs = alg_bytes / (ms * 1e-3) / 1e9
     traffic, tsrc = measured_traffic("traffic_bytes_per_launch_bf16")
+    fused_what = ("the producing block's finalize launch (per-workgroup sums -> scale / shift) + ONE conv launch on "
+                  "v_mfma_f32_16x16x32_bf16 (k_fwd16y: z-marching 8x32 columns, weights resident in accumulator registers) with "
+                  "the producing block's InstanceNorm-apply + LeakyReLU in its loader and its own statistics in the epilogue; the "
+                  "activated tensor is never written (backward: the weight-gradient kernel k_wgrad16z applies the same prologue)")
     roof = {"kernel": f"fused block Conv3d 32->32 3x3x3 + InstanceNorm3d + LeakyReLU @{'x'.join(map(str, patch))} bf16, "
-                      "batch 2, as the train step runs it: conv on v_mfma_f32_16x16x32_bf16 (z-marching 8x32 columns, weights "
-                      "resident in accumulator registers, InstanceNorm statistics in the epilogue: k_fwd16y) + the finalize "
-                      "launch + the apply pass",
+                      "batch 2, as the train step runs it: " +
+                      (fused_what if train_fused else "conv with the statistics epilogue (k_fwd16y) + the finalize launch + the "
+                                                      "apply pass"),
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_GB_per_launch": round(alg_bytes / 1e9, 4),
-            "block_ms": round(bms, 4), "ms_per_launch": round(bms, 4),
+            "block_ms": round(bms, 4), "ms_per_launch": round(bms, 4), "train_step_form": "fused" if train_fused else "unfused",
             "traffic": traffic, "traffic_source": f"{tsrc} (conv launch only, committed PMC pass, not measured in this run)",
             "conv_only": {"ms_per_launch": round(ms, 4), "achieved": round(cgbs, 1), "frac": round(cgbs / HBM_PEAK_GBS, 4),
-                          "note": "the conv launch alone against the block's byte model (round 2's `frac`)"},
+                          "note": "the plain conv launch alone against the block's byte model (round 2's `frac`)"},
             "instnorm_ms": round(bms - ms, 4),
             "mfma_view": {"tflops": round(flops / (ms * 1e-3) / 1e12, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
                           "frac": round(flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "of": "conv launch"}}
+    ug = alg_bytes / (ums * 1e-3) / 1e9
+    roof["unfused_form"] = {"block_ms": round(ums, 4), "achieved": round(ug, 1), "frac": round(ug / HBM_PEAK_GBS, 4),
+                            "what": "conv with the statistics epilogue -> finalize launch -> apply pass writing the activated "
+                                    "tensor: what blocks run whose consumer is not a z-marching 32-channel conv (and every "
+                                    "block with MVD_FUSE_PROLOGUE_TRAIN=0)"}
     if fms is not None:
         fg = alg_bytes / (fms * 1e-3) / 1e9
         roof["inference_form"] = {"block_ms": round(fms, 4), "achieved": round(fg, 1), "frac": round(fg / HBM_PEAK_GBS, 4),
-                                  "what": "the block boundary as the no-grad forward runs it (sliding-window inference): "
-                                          "finalize launch + conv with the producing block's InstanceNorm-apply + LeakyReLU "
-                                          "in its loader and its own statistics in the epilogue -- the activated tensor is "
-                                          "never written, exactly the byte model above.  Not the train step: the weight "
-                                          "gradient needs the activated tensor"}
+                                  "what": "the no-grad forward (sliding-window inference): " + fused_what}
     g, b = torch.ones(K, device=dev), torch.zeros(K, device=dev)
 
     def norm():

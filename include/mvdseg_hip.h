@@ -179,6 +179,14 @@ int mvd_set_bf16_zmarch_kernel(int which);
  * (nnUNetTrainer.py:888-925 backward): 1 (default, MVD_WGRAD16Z) = k_wgrad16z (z-marching column, csrc/conv_bf16w.hip),
  * 0 = k_wgrad16 (4x8x8 tiles).  A/B and cross-check switch. */
 int mvd_set_bf16_wgrad_kernel(int which);
+/* Weight gradient with the loader prologue (ops.NormActConv3dFn.backward; get_network_from_plans.py:41-44 fused block, the
+ * backward of nnUNetTrainer.py:888-925): x1 is the RAW bf16 output of the producing conv, the operand of the product is
+ * lrelu(x1 * in_scale[n][c] + in_shift[n][c]) rounded to bf16 -- bit-identical to mvd_conv3d_wgrad_bf16 over the tensor
+ * mvd_instnorm_lrelu_apply_bf16 would write, which therefore need not exist.  _prologue_ok: 1 when the shape is served. */
+int mvd_conv3d_wgrad_bf16_prologue_ok(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3], const int stride[3]);
+int mvd_conv3d_wgrad_bf16_fused(const uint16_t *x1, int C1, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W,
+                                int K, const int ksize[3], const int stride[3], const float *in_scale, const float *in_shift,
+                                float slope, void *ws, size_t ws_bytes, void *stream);
 /* 1 when mvd_conv3d_fwd_bf16_fused accepts in_scale / in_shift for this shape (a kernel with the loader prologue runs it) */
 int mvd_conv3d_fwd_bf16_prologue_ok(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3],
                                     const int stride[3]);

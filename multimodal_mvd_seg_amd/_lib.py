@@ -58,6 +58,9 @@ SIGNATURES = {
     "mvd_conv3d_dgrad_acc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P]),
     "mvd_conv3d_dgrad_bf16_acc": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P, c_size_t, _P]),
     "mvd_conv3d_fwd_bf16_prologue_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
+    "mvd_conv3d_wgrad_bf16_prologue_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, _I3, _I3]),
+    "mvd_conv3d_wgrad_bf16_fused": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P, _P, c_float,
+                                            _P, c_size_t, _P]),
     "mvd_instnorm_stats_bf16": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_float, _P, c_size_t, _P]),
     "mvd_conv3d_fwd_bf16_fused": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _I3, _I3, _P,
                                           _P, c_float, _P, _P, _P, c_size_t, _P]),

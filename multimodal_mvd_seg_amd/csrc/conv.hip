@@ -974,6 +974,37 @@ int mvd_conv3d_wgrad_bf16(const uint16_t *x1, int C1, const uint16_t *x2, int C2
     return 0;
 }
 
+int mvd_conv3d_wgrad_bf16_prologue_ok(int N, int D, int H, int W, int C1, int C2, int K, const int ksize[3], const int stride[3]) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || K <= 0 || check_ks(ksize, stride, "conv3d_wgrad_bf16_prologue_ok"))
+        return 0;
+    WgradGeom g;
+    conv_wgrad_geom(g, N, D, H, W, C1, C2, K, ksize, stride);
+    return wgrad16z_prologue_ok(g) ? 1 : 0;
+}
+
+int mvd_conv3d_wgrad_bf16_fused(const uint16_t *x1, int C1, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W,
+                                int K, const int ksize[3], const int stride[3], const float *in_scale, const float *in_shift,
+                                float slope, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x1 && dy && dw && ws && in_scale && in_shift && C1 > 0, "conv3d_wgrad_bf16_fused: null pointer / bad channels");
+    MVD_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && K > 0, "conv3d_wgrad_bf16_fused: bad shape");
+    if (check_ks(ksize, stride, "conv3d_wgrad_bf16_fused")) return 2;
+    WgradGeom g;
+    conv_wgrad_geom(g, N, D, H, W, C1, 0, K, ksize, stride);
+    MVD_REQUIRE(wgrad16z_prologue_ok(g), "conv3d_wgrad_bf16_fused: shape not served by the z-marching kernel (query _prologue_ok)");
+    MVD_REQUIRE(ws_bytes >= mvd_conv3d_wgrad_workspace_bytes(C1, K, g.T, N, g.Do, g.Ho, g.Wo),
+                "conv3d_wgrad_bf16_fused: workspace too small");
+    hipStream_t s = as_stream(stream);
+    int dbias_done = 0;
+    const int r = wgrad16z_run(g, x1, nullptr, dy, dw, ws, ws_bytes, s, dbias, &dbias_done, in_scale, in_shift, slope);
+    if (r < 0) {
+        set_error("conv3d_wgrad_bf16_fused: the z-marching kernel refused the launch (workspace?)");
+        return 2;
+    }
+    if (r) return r;
+    if (dbias && !dbias_done) return colsum(reinterpret_cast<const float *>(dy), dbias, (long)N * g.Do * g.Ho * g.Wo, K, ws, s, true);
+    return 0;
+}
+
 int mvd_convT3d_wgrad_bf16(const uint16_t *x, const uint16_t *dy, float *dw, float *dbias, int N, int D, int H, int W, int C, int K,
                       const int stride[3], void *ws, size_t ws_bytes, void *stream) {
     MVD_REQUIRE(x && dy && dw && ws && N > 0 && D > 0 && H > 0 && W > 0 && C > 0 && K > 0, "convT3d_wgrad_bf16: bad arguments");

@@ -39,6 +39,8 @@ typedef short s16x8w __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8z __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2z __attribute__((ext_vector_type(2)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) s16x4w lds_s16x4w;
 
 constexpr int WZ_TH = 8, WZ_TW = 32;
@@ -97,11 +99,18 @@ __device__ inline void wz_wait(u32x4z (&r)[CNT]) {  // s_waitcnt vmcnt(N); the s
 // 2.16 GHz; everything but the MFMAs 97 us at 2.51 GHz -- MFMA stream plus HBM stream run into the power limit, so the
 // parts "add up" in time although they overlap in cycles.  NG = 2 hides the operand reads (plane loop without staging
 // 0.142 vs 0.161 ms) but not that.
-template <int DBG, int NG>
+// PRO: loader prologue (ops.NormActConv3dFn backward): x is the RAW bf16 output of the producing conv; the operand of the
+// product is a = bf16(lrelu(fma(x, scale[n][c], shift[n][c]))) -- the arithmetic of k_in_apply_ss16 / the forward loader
+// prologue of k_fwd16y, applied to the staged 16-byte parts in registers (a thread's parts are always the channel octet
+// tid & 3: eight scale / shift registers), one part per step ten steps ahead of its LDS write; voxels outside the volume
+// stay zero (the zero padding applies to the activation).  The activated tensor is never read: it need not exist.
+template <int DBG, int NG, bool PRO>
 __global__ __launch_bounds__(256 * NG, 1) void k_wgrad16z(const WgradGeom g, const WgZTile tg, const unsigned short *__restrict__ a1,
                                                           const unsigned short *__restrict__ a2,
                                                           const unsigned short *__restrict__ b, float *__restrict__ partial,
-                                                          float *__restrict__ pbias) {
+                                                          float *__restrict__ pbias, const float *__restrict__ in_scale,
+                                                          const float *__restrict__ in_shift, const float slope) {
+    static_assert(!PRO || NG == 1, "the loader prologue is scheduled for the four-wave form");
     constexpr int NT = 256 * NG;                     // threads
     constexpr int NA = (WZ_APARTS + NT - 1) / NT;    // staging loads per thread: x plane (6 / 3)
     constexpr int NB = WZ_TH * WZ_TW * 4 / NT;       // dy plane (4 / 2)
@@ -188,6 +197,29 @@ __global__ __launch_bounds__(256 * NG, 1) void k_wgrad16z(const WgradGeom g, con
             const bool ok = y0 + r < H && x0 + c < W;
             voB[u] = ok ? (unsigned)(((r * W + c) * K) * 2 + (idx & 3) * 16) : 0x80000000u;
         }
+        float psc[PRO ? 8 : 1], psh[PRO ? 8 : 1];
+        if (PRO) {
+            const float *sp = in_scale + (size_t)n * g.C1 + c0 + (tid & 3) * 8, *tp = in_shift + (size_t)n * g.C1 + c0 + (tid & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                psc[e] = sp[e];
+                psh[e] = tp[e];
+            }
+        }
+        auto xform = [&](u32x4z &q, const bool ok) {  // (same expression as k_fwd16y's prologue: bit-identical activations)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float lo = __uint_as_float(q[e] << 16), hi = __uint_as_float(q[e] & 0xffff0000u);
+                lo = __builtin_fmaf(lo, psc[2 * e], psh[2 * e]);
+                hi = __builtin_fmaf(hi, psc[2 * e + 1], psh[2 * e + 1]);
+                lo = fmaxf(lo, lo * slope);
+                hi = fmaxf(hi, hi * slope);
+                f32x2w v2 = {lo, hi};
+                bf16x2w r2 = __builtin_convertvector(v2, bf16x2w);
+                q[e] = ok ? *reinterpret_cast<unsigned *>(&r2) : 0u;
+            }
+        };
+        auto plane_ok = [&](int z) { return z >= 0 && z < D; };
         // corner addresses of plane 0 of this sample (the corner itself may lie outside the volume: only valid lanes load)
         const long planeA = (long)H * W * Cs * 2, planeB = (long)H * W * K * 2;
         const char *cornerA = reinterpret_cast<const char *>(asrc) + ((long)n * D * planeA + ((long)(y0 - 1) * W + (x0 - 1)) * Cs * 2 + cofs * 2);
@@ -230,17 +262,34 @@ __global__ __launch_bounds__(256 * NG, 1) void k_wgrad16z(const WgradGeom g, con
             load_A(ra[1], rsrcA(z0 + 1));
             load_B(rb[0], rsrcB(z0, true));
             wz_wait<2 * NA + NB>(r0);
+            if (PRO) {
+#pragma unroll
+                for (int u = 0; u < NA; u++) xform(r0[u], voA[u] != 0x80000000u && plane_ok(z0 - 1));
+            }
             write_A(0, r0);
             wz_wait<NA + NB>(ra[0]);
+            if (PRO) {
+#pragma unroll
+                for (int u = 0; u < NA; u++) xform(ra[0][u], voA[u] != 0x80000000u && plane_ok(z0));
+            }
             write_A(1, ra[0]);
             wz_wait<0>(ra[1]);
             wz_wait<0>(rb[0]);
+            if (PRO) {
+#pragma unroll
+                for (int u = 0; u < NA; u++) xform(ra[1][u], voA[u] != 0x80000000u && plane_ok(z0 + 1));
+            }
             write_A(2, ra[1]);
             write_B(0, rb[0]);
             load_A(ra[0], rsrcA(2 <= nz ? z0 + 2 : -1));
             load_B(rb[0], rsrcB(z0 + 1, 1 < nz));
             load_A(ra[1], rsrcA(3 <= nz ? z0 + 3 : -1));
             load_B(rb[1], rsrcB(z0 + 2, 2 < nz));
+            if (PRO) {  // set 0 is written by plane 0 before any step could transform it (set 1: steps 10 .. 15 of plane 0)
+                wz_wait<NA + NB>(ra[0]);
+#pragma unroll
+                for (int u = 0; u < NA; u++) xform(ra[0][u], voA[u] != 0x80000000u && 2 <= nz && plane_ok(z0 + 2));
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -311,6 +360,19 @@ __global__ __launch_bounds__(256 * NG, 1) void k_wgrad16z(const WgradGeom g, con
                 if (DBG & (2 | 32)) {
                 } else if (st >= ST_LD0 && st < ST_LD0 + NA) wz_bload(ra[SET][st - ST_LD0], voA[st - ST_LD0], rA);
                 else if (st >= ST_LD0 + NA && st < ST_LD0 + NA + NB) wz_bload(rb[SET][st - ST_LD0 - NA], voB[st - ST_LD0 - NA], rB);
+                constexpr int ST_X0 = ST_LD0 + NB;  // PRO: part u of the OTHER set (x plane z + 3, loaded one plane ago) at step
+                if (PRO && st >= ST_X0 && st < ST_X0 + NA) {  // ST_X0 + u: every younger load is one of this plane's
+                    // the other set is complete once no more loads are outstanding than this plane has issued so far
+                    constexpr int Y0 = ST_X0 - ST_LD0 + 1;
+                    const int u_ = st - ST_X0;
+                    if (u_ == 0) wz_wait<Y0>(ra[1 - SET]);
+                    else if (u_ == 1) wz_wait<Y0 + 1>(ra[1 - SET]);
+                    else if (u_ == 2) wz_wait<Y0 + 2>(ra[1 - SET]);
+                    else if (u_ == 3) wz_wait<Y0 + 3>(ra[1 - SET]);
+                    else if (u_ == 4) wz_wait<Y0 + 4>(ra[1 - SET]);
+                    else wz_wait<Y0 + 5>(ra[1 - SET]);
+                    xform(ra[1 - SET][st - ST_X0], voA[st - ST_X0] != 0x80000000u && p + 3 <= nz && plane_ok(z + 3));
+                }
                 if (!(DBG & 8)) mfmas(st & 1);
                 if (st == ST_WA && !(DBG & (2 | 64))) {
                     wz_wait<2 * (NA + NB) - NA>(ra[SET]);  // (this set's loads are the older half of those outstanding)
@@ -328,6 +390,7 @@ __global__ __launch_bounds__(256 * NG, 1) void k_wgrad16z(const WgradGeom g, con
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (j < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                         if (j >= 1 && j < 5) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        if (PRO && st >= ST_X0 && st < ST_X0 + NA) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
                         if ((st == ST_WA && j < NA) || (st == ST_WB && j < NB)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                     }
                 }
@@ -386,21 +449,31 @@ void wgrad16z_enable(int on) { wgrad16z_mode() = on; }
 
 // Returns -1 when the problem is not this kernel's (the caller falls through to k_wgrad16), 0 after a launch (the partials
 // [nsplit][27][C][K] and, when pbias_out is set, the bias rows [nsplit][K] are in ws), > 0 on error.
-int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,
-             size_t ws_bytes, bool want_bias, int *nsplit_out, float **pbias_out, hipStream_t s) {
-    if (!wgrad16z_mode()) return -1;
+static bool wgrad16z_shape_ok(const WgradGeom &g) {
     const int C = g.C1 + g.C2;
-    if (g.ntaps != 27 || g.T != 27 || g.C1 % 32 != 0 || g.C2 % 32 != 0 || g.K % 32 != 0 || C < 32) return -1;
-    if (g.Di != g.Do || g.Hi != g.Ho || g.Wi != g.Wo || g.Db != g.Do || g.Hb != g.Ho || g.Wb != g.Wo) return -1;
+    if (g.ntaps != 27 || g.T != 27 || g.C1 % 32 != 0 || g.C2 % 32 != 0 || g.K % 32 != 0 || C < 32) return false;
+    if (g.Di != g.Do || g.Hi != g.Ho || g.Wi != g.Wo || g.Db != g.Do || g.Hb != g.Ho || g.Wb != g.Wo) return false;
     for (int a = 0; a < 3; a++)
-        if (g.sa[a] != 1 || g.sb[a] != 1) return -1;
+        if (g.sa[a] != 1 || g.sb[a] != 1) return false;
     for (int t = 0; t < 27; t++)
         if (g.off[t][0] != t / 9 - 1 || g.off[t][1] != (t / 3) % 3 - 1 || g.off[t][2] != t % 3 - 1 || g.ob[t][0] != 0 ||
             g.ob[t][1] != 0 || g.ob[t][2] != 0)
-            return -1;
-    if (g.Wo < 32 || g.Ho < 8 || g.Do < 8) return -1;
+            return false;
+    if (g.Wo < 32 || g.Ho < 8 || g.Do < 8) return false;
     // 32-bit lane offsets inside a plane, 64-bit scalar plane bases
-    if ((long)g.Ho * g.Wo * (g.C1 > g.C2 ? g.C1 : g.C2) * 2 >= (1L << 31) || (long)g.Ho * g.Wo * g.K * 2 >= (1L << 31)) return -1;
+    if ((long)g.Ho * g.Wo * (g.C1 > g.C2 ? g.C1 : g.C2) * 2 >= (1L << 31) || (long)g.Ho * g.Wo * g.K * 2 >= (1L << 31)) return false;
+    return true;
+}
+
+bool wgrad16z_prologue_ok(const WgradGeom &g) { return wgrad16z_shape_ok(g) && g.C2 == 0; }
+
+int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,
+             size_t ws_bytes, bool want_bias, int *nsplit_out, float **pbias_out, hipStream_t s, const float *in_scale,
+             const float *in_shift, float slope) {
+    const bool pro = in_scale != nullptr && in_shift != nullptr;
+    if (!wgrad16z_mode() && !pro) return -1;
+    if (!wgrad16z_shape_ok(g) || (pro && g.C2 != 0)) return -1;
+    const int C = g.C1 + g.C2;
     WgZTile tg;
     tg.nty = (g.Ho + WZ_TH - 1) / WZ_TH;
     tg.ntx = (g.Wo + WZ_TW - 1) / WZ_TW;
@@ -437,27 +510,30 @@ int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short 
     float *partial = reinterpret_cast<float *>(ws);
     float *pbias = want_bias ? partial + need / sizeof(float) : nullptr;
     typedef void (*kfn_t)(const WgradGeom, const WgZTile, const unsigned short *, const unsigned short *, const unsigned short *,
-                          float *, float *);
+                          float *, float *, const float *, const float *, float);
     // wave groups: 1 (default) = four waves, 2 = eight.  Measured equal inside the step (11.27-11.41 vs 11.39-11.48 ms): with
     // the staging traffic on, the kernel runs against the power limit (1.76 GHz; 2.16 GHz for the MFMA stream alone), where
     // the cycles the second wave per SIMD saves (340 k -> 300 k per XCD without staging) do not turn into time
-    static const int ng = getenv("MVD_WGRAD16Z_NG") ? (atoi(getenv("MVD_WGRAD16Z_NG")) == 2 ? 2 : 1) : 1;
-    kfn_t kfn = ng == 2 ? k_wgrad16z<0, 2> : k_wgrad16z<0, 1>;
+    static const int ng_env = getenv("MVD_WGRAD16Z_NG") ? (atoi(getenv("MVD_WGRAD16Z_NG")) == 2 ? 2 : 1) : 1;
+    const int ng = pro ? 1 : ng_env;
+    kfn_t kfn = pro ? k_wgrad16z<0, 1, true> : ng == 2 ? k_wgrad16z<0, 2, false> : k_wgrad16z<0, 1, false>;
 #ifdef MVD_WG16Z_ABLATE
     static const int dbg = getenv("MVD_WG16Z_DBG") ? atoi(getenv("MVD_WG16Z_DBG")) : 0;  // timing ablation only: results are wrong
-#define WZ_DBG(V) if (dbg == V) kfn = ng == 2 ? k_wgrad16z<V, 2> : k_wgrad16z<V, 1>;
+#define WZ_DBG(V) if (dbg == V && !pro) kfn = ng == 2 ? k_wgrad16z<V, 2, false> : k_wgrad16z<V, 1, false>;
     WZ_DBG(1) WZ_DBG(2) WZ_DBG(3) WZ_DBG(4) WZ_DBG(8) WZ_DBG(16) WZ_DBG(32) WZ_DBG(64) WZ_DBG(128) WZ_DBG(129) WZ_DBG(130) WZ_DBG(131) WZ_DBG(160) WZ_DBG(192) WZ_DBG(136) WZ_DBG(132)
 #undef WZ_DBG
 #endif
-    static PerDeviceFlag cfgd;
-    if (!cfgd()) {
+    static PerDeviceFlag cfgd, cfgd_pro;
+    PerDeviceFlag &cf = pro ? cfgd_pro : cfgd;
+    if (!cf()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, WZ_LDS) != hipSuccess) {
             set_error("conv wgrad (bf16 z-marching): cannot raise the dynamic LDS limit");
             return 1;
         }
-        cfgd() = true;
+        cf() = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(tg.nsplit, (unsigned)blocks), dim3(256 * ng), WZ_LDS, s, g, tg, a1, a2, b, partial, pbias);
+    hipLaunchKernelGGL(kfn, dim3(tg.nsplit, (unsigned)blocks), dim3(256 * ng), WZ_LDS, s, g, tg, a1, a2, b, partial, pbias, in_scale, in_shift,
+                       slope);
     if (check_launch("conv wgrad (bf16 z-marching)")) return 1;
     *nsplit_out = tg.nsplit;
     *pbias_out = pbias;

@@ -89,7 +89,13 @@ int dgrad16s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, c
 // bf16 z-marching weight gradient of the plain 3x3x3 stride-1 conv (conv_bf16w.hip): -1 = not this kernel's problem, 0 = the
 // partials [nsplit][27][C][K] (and, if asked, bias rows [nsplit][K] at *pbias_out) are in ws
 int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,
-             size_t ws_bytes, bool want_bias, int *nsplit_out, float **pbias_out, hipStream_t s);
+             size_t ws_bytes, bool want_bias, int *nsplit_out, float **pbias_out, hipStream_t s, const float *in_scale = nullptr,
+             const float *in_shift = nullptr, float slope = 0.f);
+// the same + the split reduce into dw / dbias (conv_mfma.hip)
+int wgrad16z_run(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, float *dw, void *ws,
+                 size_t ws_bytes, hipStream_t s, float *dbias, int *dbias_done, const float *in_scale, const float *in_shift,
+                 float slope);
+bool wgrad16z_prologue_ok(const WgradGeom &g);
 void wgrad16z_enable(int on);
 int pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf, float *const *ub,
                        const int *K, const int *C, const int *T, const int *transposed, hipStream_t s);

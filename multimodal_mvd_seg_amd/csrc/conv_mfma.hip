@@ -2753,6 +2753,29 @@ size_t wgrad_mfma_ws(const WgradGeom &g) {
     return (size_t)wgrad_max_split(g) * (g.ntaps * (size_t)(g.C1 + g.C2) + 2) * g.K * sizeof(float) + 256;
 }
 
+// k_wgrad16z + the split reduce.  -1 = not that kernel's problem.  in_scale / in_shift (optional, [N][C1] fp32): the loader
+// prologue -- x is the RAW output of the producing conv and the operand is lrelu(x * scale + shift) (ops.NormActConv3dFn)
+int wgrad16z_run(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, float *dw, void *ws,
+                 size_t ws_bytes, hipStream_t s, float *dbias, int *dbias_done, const float *in_scale, const float *in_shift,
+                 float slope) {
+    int nsplit_z = 0;
+    float *pbias_z = nullptr;
+    const int C = g.C1 + g.C2;
+    const int rz = wgrad16z(g, a1, a2, b, ws, ws_bytes, dbias && dbias_done, &nsplit_z, &pbias_z, s, in_scale, in_shift, slope);
+    if (rz != 0) return rz;
+    float *partial_z = reinterpret_cast<float *>(ws);
+    const int wblocks = (int)cdiv((long)27 * C * g.K, 64);
+    if (pbias_z) {
+        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks + cdiv(g.K, 64)), dim3(256), 0, s, g, partial_z, dw, nsplit_z, pbias_z, dbias,
+                           nsplit_z, wblocks);
+        *dbias_done = 1;
+    } else {
+        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks), dim3(256), 0, s, g, partial_z, dw, nsplit_z, (const float *)nullptr,
+                           (float *)nullptr, 0, 0);
+    }
+    return check_launch("conv wgrad reduce (bf16 z-marching)");
+}
+
 int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float *b, float *dw, void *ws, size_t ws_bytes,
                hipStream_t s, bool bf16_in, float *dbias, int *dbias_done) {
     if (dbias_done) *dbias_done = 0;
@@ -2761,24 +2784,10 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     if (bf16_in && (g.C1 % 32 != 0 || g.C2 % 32 != 0 || g.K % 32 != 0)) return -1;
     const int C = g.C1 + g.C2;
     if (bf16_in) {  // plain 3x3x3 stride 1 on volumes at least 32 wide: the z-marching kernel (conv_bf16w.hip)
-        int nsplit_z = 0;
-        float *pbias_z = nullptr;
-        const int rz = wgrad16z(g, reinterpret_cast<const unsigned short *>(a1), reinterpret_cast<const unsigned short *>(a2),
-                                reinterpret_cast<const unsigned short *>(b), ws, ws_bytes, dbias && dbias_done, &nsplit_z, &pbias_z, s);
-        if (rz > 0) return rz;
-        if (rz == 0) {
-            float *partial_z = reinterpret_cast<float *>(ws);
-            const int wblocks = (int)cdiv((long)27 * C * g.K, 64);
-            if (pbias_z) {
-                hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks + cdiv(g.K, 64)), dim3(256), 0, s, g, partial_z, dw, nsplit_z, pbias_z,
-                                   dbias, nsplit_z, wblocks);
-                *dbias_done = 1;
-            } else {
-                hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks), dim3(256), 0, s, g, partial_z, dw, nsplit_z, (const float *)nullptr,
-                                   (float *)nullptr, 0, 0);
-            }
-            return check_launch("conv wgrad reduce (bf16 z-marching)");
-        }
+        const int rz = wgrad16z_run(g, reinterpret_cast<const unsigned short *>(a1), reinterpret_cast<const unsigned short *>(a2),
+                                    reinterpret_cast<const unsigned short *>(b), dw, ws, ws_bytes, s, dbias, dbias_done, nullptr,
+                                    nullptr, 0.f);
+        if (rz >= 0) return rz;
     }
     WgTile tg;
     memset(&tg, 0, sizeof(tg));

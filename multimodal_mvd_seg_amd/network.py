@@ -19,11 +19,13 @@ from . import ops
 
 
 # InstanceNorm-apply + LeakyReLU in the consumer conv's loader (bf16, z-marching kernel): on in inference; under autograd
-# only on request (the weight gradient needs the activated tensor and re-materialises it)
+# ("auto", the default) where the weight-gradient kernel has the same prologue (k_wgrad16z: the activated tensor is then
+# written in neither pass), "1" = wherever the forward kernel takes it (the weight gradient of other shapes re-materialises
+# the tensor), "0" = never
 # gradient contributions of a tensor with two consumers summed inside the second consumer's kernel (ops._GradShare)
 SHARE_GRADS = [os.environ.get("MVD_SHARE_GRADS", "1") != "0"]
 FUSE_PROLOGUE = [os.environ.get("MVD_FUSE_PROLOGUE", "1") != "0"]
-FUSE_PROLOGUE_TRAIN = [os.environ.get("MVD_FUSE_PROLOGUE_TRAIN", "0") == "1"]
+FUSE_PROLOGUE_TRAIN = [os.environ.get("MVD_FUSE_PROLOGUE_TRAIN", "auto")]
 
 
 def _tup3(v):
@@ -143,8 +145,8 @@ class StackedConvBlocks(nn.Module):
     def forward(self, x, x2=None):
         """conv -> norm -> act per block.  bf16 mixed precision, consecutive blocks whose second conv takes the z-marching
         kernel (3x3x3, stride 1, 32 -> 32 channels at the patch resolution): the first block's InstanceNorm + LeakyReLU is
-        folded into the second conv's loader (no apply pass, the activated tensor is never written) -- in inference
-        (no autograd), or under autograd with MVD_FUSE_PROLOGUE_TRAIN=1 (there the weight gradient re-materialises it)."""
+        folded into the second conv's loader (no apply pass, the activated tensor is never written) --
+        in inference and, where the weight-gradient kernel has the same prologue, in training (FUSE_PROLOGUE_TRAIN)."""
         blocks = list(self.convs)
         raw = None   # the raw conv output of the previous block when its norm + act are still pending
         for i, blk in enumerate(blocks):
@@ -165,14 +167,20 @@ class StackedConvBlocks(nn.Module):
     @staticmethod
     def _can_fuse(blk, nxt, inp):
         """Shape-only test (before anything runs) whether blk's InstanceNorm + LeakyReLU can ride in nxt's conv loader."""
-        if not (blk.precision == "bf16" and FUSE_PROLOGUE[0] and (not torch.is_grad_enabled() or FUSE_PROLOGUE_TRAIN[0])):
+        train = torch.is_grad_enabled()
+        mode = str(FUSE_PROLOGUE_TRAIN[0]).lower()
+        if not (blk.precision == "bf16" and FUSE_PROLOGUE[0]) or (train and mode in ("0", "false")):
             return False
         w = nxt.conv.weight
         if tuple(w.shape[2:]) != (3, 3, 3) or nxt.stride != (1, 1, 1) or w.shape[1] != blk.output_channels or not inp.is_cuda:
             return False
         sp = [(d + 2 * ((k - 1) // 2) - k) // st + 1 for d, k, st in zip(inp.shape[2:], blk.conv.kernel_size, blk.stride)]
-        return ops.query("mvd_conv3d_fwd_bf16_prologue_ok", inp.shape[0], sp[0], sp[1], sp[2], blk.output_channels, 0,
-                         w.shape[0], ops.i3((3, 3, 3)), ops.i3((1, 1, 1))) > 0
+        shape = (inp.shape[0], sp[0], sp[1], sp[2], blk.output_channels, 0, w.shape[0], ops.i3((3, 3, 3)), ops.i3((1, 1, 1)))
+        if ops.query("mvd_conv3d_fwd_bf16_prologue_ok", *shape) <= 0:
+            return False
+        if train and mode not in ("1", "true"):   # "auto": only where the weight gradient has the prologue too
+            return ops.WGRAD_PROLOGUE and ops.query("mvd_conv3d_wgrad_bf16_prologue_ok", *shape) > 0
+        return True
 
     def compute_conv_feature_map_size(self, input_size):
         output = self.convs[0].compute_conv_feature_map_size(input_size)

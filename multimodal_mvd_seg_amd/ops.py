@@ -814,14 +814,20 @@ class InstanceNormLeakyReLUFn(Function):
         return dx, dg, db, None, None, None
 
 
+# NormActConv3dFn.backward: take the weight gradient through the loader prologue of k_wgrad16z (0: re-materialise the
+# activated tensor with one apply pass first -- the A/B and cross-check switch)
+WGRAD_PROLOGUE = os.environ.get("MVD_WGRAD_PROLOGUE", "1") != "0"
+
+
 class NormActConv3dFn(Function):
     """The fused block boundary of the north_star (get_network_from_plans.py:41-44, bf16 mixed precision): InstanceNorm3d(affine)
     + LeakyReLU of block k folded into the LOADER of block k+1's Conv3d 3x3x3 (mvd_conv3d_fwd_bf16_fused: z-marching
     kernel, 32 -> 32 channels).  Input `y0` is the RAW bf16 output of block k's conv carrying the statistics its epilogue
     emitted (`_mvd_tile_stats16`); the activated tensor a0 = lrelu(IN(y0)) is never written in the forward pass.
     Backward: dgrad -> d a0; the InstanceNorm backward kernels on (y0, d a0) -> d y0, d gamma, d beta; the weight gradient
-    needs a0 itself, which is re-materialised by one apply pass (so under autograd the fusion moves that pass from the
-    forward to the backward step: it pays in inference, and saves the activation's memory in training)."""
+    needs a0 as an operand: mvd_conv3d_wgrad_bf16_fused re-computes it from y0 in ITS loader (k_wgrad16z, same arithmetic:
+    bit-identical to the gradient over the materialised tensor), so a0 exists in neither pass.  Shapes that kernel does not
+    serve fall back to one apply pass in front of the plain weight-gradient call."""
 
     @staticmethod
     def forward(ctx, y0, gamma, beta, eps, slope, weight, bias):
@@ -837,6 +843,11 @@ class NormActConv3dFn(Function):
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         mean = torch.empty((N, C), dtype=torch.float32, device=y0.device)
         rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+        tm = LAUNCH_TIMER   # bench.py: the fused block (finalize + conv) inside the step
+        timed = tm is not None and tm.on and tm.key == (True, N, C, 0, K, D, H, W, (3, 3, 3), (1, 1, 1))
+        if timed:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if pre is not None and pre[0].shape[0] == N and pre[0].shape[2] == C:
             call("mvd_instnorm_finalize_tiles", _p(pre[0]), pre[1], _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N,
                  V, C, float(eps), _stream())
@@ -848,6 +859,10 @@ class NormActConv3dFn(Function):
         y1 = empty_cl3d((N, K, D, H, W), y0.device, BF16)
         ws = _Workspace.get(query("mvd_conv_fwd_workspace_bytes", N, V, K), y0.device)
         conv3d_fwd_bf16(y0, C, None, 0, wf, bias, y1, N, D, H, W, K, (3, 3, 3), (1, 1, 1), ws, scale, shift, slope)
+        if timed:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            tm.pairs.append((ev0, ev1))
         ctx.save_for_backward(y0, g, b, mean, rstd, scale, shift, wb)
         ctx.params = (gamma, beta, weight, bias)
         ctx.slope = float(slope)
@@ -886,15 +901,21 @@ class NormActConv3dFn(Function):
                 db_ = None
                 _grad_done(beta)
         if ctx.needs_input_grad[5]:
-            a0 = empty_cl3d(y0.shape, dev, BF16)  # the activated tensor, only now (and only for the weight gradient)
-            call("mvd_instnorm_lrelu_apply_bf16", _p(y0), _p(scale), _p(shift), _p(a0), N, V, C, ctx.slope, _stream())
             has_bias = bias is not None
             sink_w, sink_b2 = _take_grad(weight), (_take_grad(bias) if has_bias else None)
             dw = sink_w if sink_w is not None else torch.empty((K, C, 3, 3, 3), dtype=torch.float32, device=dev)
             db = (sink_b2 if sink_b2 is not None else torch.empty((K,), dtype=torch.float32, device=dev)) if has_bias else None
             ws = _Workspace.get(query("mvd_conv3d_wgrad_workspace_bytes", C, K, 27, N, D, H, W), dev)
-            call("mvd_conv3d_wgrad_bf16", _p(a0), C, None, 0, _p(dy1), _p(dw), _p(db), N, D, H, W, K, ks, st, _p(ws),
-                 ws.numel(), _stream())
+            if WGRAD_PROLOGUE and query("mvd_conv3d_wgrad_bf16_prologue_ok", N, D, H, W, C, 0, K, ks, st) > 0:
+                # the weight-gradient kernel applies the same InstanceNorm + LeakyReLU to y0 in its loader: the activated
+                # tensor is never materialised, in neither pass
+                call("mvd_conv3d_wgrad_bf16_fused", _p(y0), C, _p(dy1), _p(dw), _p(db), N, D, H, W, K, ks, st, _p(scale),
+                     _p(shift), ctx.slope, _p(ws), ws.numel(), _stream())
+            else:
+                a0 = empty_cl3d(y0.shape, dev, BF16)  # the activated tensor, only now (and only for the weight gradient)
+                call("mvd_instnorm_lrelu_apply_bf16", _p(y0), _p(scale), _p(shift), _p(a0), N, V, C, ctx.slope, _stream())
+                call("mvd_conv3d_wgrad_bf16", _p(a0), C, None, 0, _p(dy1), _p(dw), _p(db), N, D, H, W, K, ks, st, _p(ws),
+                     ws.numel(), _stream())
             if sink_w is not None:
                 dw = None
                 _grad_done(weight)

@@ -434,3 +434,78 @@ def test_wgrad16z_random_data_against_fp64():
     ops.Conv3dFn.apply(gx, None, gw, None, (1, 1, 1)).backward(gy.to(DEV).contiguous(memory_format=CL))
     err = (gw.grad.cpu().double() - wr.grad).abs().max()
     assert float(err) <= 1e-5 * float(wr.grad.abs().max()) + 1e-3, float(err)  # fp32 accumulation of exact bf16 products
+
+
+@pytest.mark.parametrize("C,K,N,D,H,W", [(32, 32, 2, 52, 60, 44), (32, 32, 1, 33, 70, 97), (64, 64, 2, 40, 41, 66), (32, 64, 1, 9, 8, 32),
+                                          (32, 32, 2, 128, 64, 64)])
+def test_wgrad_loader_prologue_equals_the_gradient_over_the_materialised_activation_bit_for_bit(C, K, N, D, H, W):
+    """mvd_conv3d_wgrad_bf16_fused (k_wgrad16z with the InstanceNorm-apply + LeakyReLU prologue on the staged x planes) ==
+    mvd_conv3d_wgrad_bf16 over the tensor mvd_instnorm_lrelu_apply_bf16 writes: same activations bit for bit (one
+    expression), same MFMA sequence -> torch.equal on dw and db; per-sample scale / shift, ragged volumes (voxels outside
+    the volume must stay ZERO, not lrelu(shift)), chunked z ranges, 64 channels in two blocks."""
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    g = torch.Generator().manual_seed(C + D + W)
+    y0 = torch.randn(N, C, D, H, W, generator=g).to(BF).to(DEV).contiguous(memory_format=CL)
+    dy = torch.randn(N, K, D, H, W, generator=g).to(BF).to(DEV).contiguous(memory_format=CL)
+    scale = (torch.rand(N, C, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(N, C, generator=g) * 0.5).to(DEV)   # non-zero shift: lrelu(shift) != 0 would leak through a padding bug
+    ks, st = i3((3, 3, 3)), i3((1, 1, 1))
+    assert query("mvd_conv3d_wgrad_bf16_prologue_ok", N, D, H, W, C, 0, K, ks, st) == 1
+    a0 = torch.empty_like(y0)
+    call("mvd_instnorm_lrelu_apply_bf16", _p(y0), _p(scale), _p(shift), _p(a0), N, D * H * W, C, 0.01, _stream())
+    ws = torch.empty(query("mvd_conv3d_wgrad_workspace_bytes", C, K, 27, N, D, H, W), dtype=torch.uint8, device=DEV)
+    dw1, db1 = torch.empty(K, C, 3, 3, 3, device=DEV), torch.empty(K, device=DEV)
+    dw2, db2 = torch.empty_like(dw1), torch.empty_like(db1)
+    call("mvd_conv3d_wgrad_bf16", _p(a0), C, None, 0, _p(dy), _p(dw1), _p(db1), N, D, H, W, K, ks, st, _p(ws), ws.numel(), _stream())
+    call("mvd_conv3d_wgrad_bf16_fused", _p(y0), C, _p(dy), _p(dw2), _p(db2), N, D, H, W, K, ks, st, _p(scale), _p(shift), 0.01,
+         _p(ws), ws.numel(), _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2), f"{int((dw1 != dw2).sum())} of {dw1.numel()} differ, max {float((dw1 - dw2).abs().max())}"
+    assert torch.equal(db1, db2)
+    # and against fp64 over the same activations
+    ref = torch.autograd.grad(F.conv3d(a0.double().cpu(), (w := torch.zeros(K, C, 3, 3, 3, dtype=torch.float64, requires_grad=True)),
+                                       None, 1, 1), w, dy.double().cpu())[0] if D * H * W * N <= 200000 else None
+    if ref is not None:
+        assert float((dw2.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-3
+    # shapes the kernel does not serve are refused, not mis-computed
+    assert query("mvd_conv3d_wgrad_bf16_prologue_ok", N, D, H, 16, C, 0, K, ks, st) == 0
+    assert query("mvd_conv3d_wgrad_bf16_prologue_ok", N, D, H, W, C, 32, K, ks, st) == 0
+
+
+def test_train_step_with_the_fused_block_in_training_is_bit_identical_to_the_unfused_step():
+    """bf16 train steps with the block boundary fused in TRAINING (forward: IN-apply + LeakyReLU in the next conv's loader;
+    backward: the same prologue in the weight-gradient kernel; the activated tensor is never written) against the same steps
+    with MVD_FUSE_PROLOGUE_TRAIN=0: every value that flows is the same, so loss and parameters agree bit for bit."""
+    from multimodal_mvd_seg_amd import network, trainer
+    strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
+    plans = trainer.make_plans((64, 64, 64), strides, batch_size=2)
+    ds = {"channel_names": {str(i): f"m{i}" for i in range(4)}, "labels": {"background": 0, "a": 1, "b": 2, "c": 3, "d": 4}}
+    res, counts = [], {}
+    saved = network.FUSE_PROLOGUE_TRAIN[0]
+    try:
+        for mode in ("auto", "0"):
+            network.FUSE_PROLOGUE_TRAIN[0] = mode
+            tr = trainer.nnUNetTrainerMI355(plans, "3d_fullres", 0, ds, device=DEV)
+            tr.precision = "bf16"
+            tr.use_hip_graph = False
+            torch.manual_seed(0)
+            tr.initialize()
+            n_fused = [0]
+            orig_call = network.ops.call
+
+            def counting_call(name, *a, **k):
+                n_fused[0] += name == "mvd_conv3d_wgrad_bf16_fused"
+                return orig_call(name, *a, **k)
+            network.ops.call = counting_call
+            try:
+                losses = [float(tr.train_step(tr.make_dummy_batch(seed=4 + i))["loss"]) for i in range(2)]
+            finally:
+                network.ops.call = orig_call
+            counts[mode] = n_fused[0]
+            res.append((losses, [p.detach().clone() for p in tr.network.parameters()]))
+    finally:
+        network.FUSE_PROLOGUE_TRAIN[0] = saved
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for p, q in zip(res[0][1], res[1][1]):
+        assert torch.equal(p, q)
+    assert counts["auto"] >= 2 and counts["0"] == 0, counts   # the fused weight gradient really ran (once per step) in "auto"
