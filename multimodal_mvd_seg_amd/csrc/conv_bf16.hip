@@ -1840,6 +1840,10 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
             if (r >= 0) return r;
         }
     }
+    // (3x3x3 stride 2, tried in round 3: a 2 x 4 x 8 output tile on two waves -- 765 halo slots, two workgroups per CU so that one's
+    // halo fetch overlaps the other's MFMAs -- measured SLOWER than the 4 x 4 x 8 tile below: 32 -> 64 @128^3 0.295 vs 0.229 ms,
+    // 64 -> 128 @64^3 0.111 vs 0.089.  The time of these launches is the per-tap-group weight staging through LDS with its
+    // barriers, not the halo: the fix is a z-marching kernel with register-resident weights and a parity-split LDS image.)
     // tile candidates: 4x8x8 (MT = 2) when its halo fits 640 slots, else 4x4x8
     for (int MT = 2; MT >= 1; MT--) {
         Fwd16Tile tg;
