@@ -20,6 +20,27 @@ stats() {  # tag, bench args...
   tail -1 $OUT/$tag.log | cut -c1-300
   rm -rf $OUT/$tag
 }
+# the bench lines themselves, without the profiler (fp32 default line incl. secondary.bf16; the other BASELINE configs)
+plain() {  # tag, bench args...
+  tag=$1; shift
+  python3 $ROOT/bench.py "$@" > $OUT/plain_$tag.json 2> $OUT/plain_$tag.err || echo "plain $tag failed"
+  tail -1 $OUT/plain_$tag.json | cut -c1-200
+}
+plain default --gpus 1 --steps 20 --warmup 5
+plain bf16 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline
+plain cfg3 --config cfg3 --steps 10 --warmup 5 --no-cpu-baseline --no-roofline
+plain cfg4 --config cfg4 --steps 10 --warmup 5 --no-cpu-baseline --no-roofline
+plain cfg5 --config cfg5 --steps 10 --warmup 5 --no-cpu-baseline --no-roofline
+python3 - <<PY
+import json
+out = {}
+for t in ("default", "bf16", "cfg3", "cfg4", "cfg5"):
+    try:
+        out[t] = json.loads(open("$OUT/plain_%s.json" % t).read().strip().splitlines()[-1])
+    except Exception as e:
+        out[t] = {"error": str(e)}
+json.dump(out, open("$OUT/${RR}_bench_lines.json", "w"), indent=1)
+PY
 stats bench
 stats bench_bf16 --precision bf16
 stats bench_cfg3 --config cfg3
@@ -45,7 +66,7 @@ pmc() {  # tag layer what dtype
 pmc fwd16y_32_32 dec5.conv1 fwd bf16
 pmc fwd16y_64_32 dec5.conv0 fwd bf16
 pmc dgrad16s enc1.conv0 dgrad bf16
-pmc wgrad16 dec5.conv1 wgrad bf16
+pmc wgrad16z dec5.conv1 wgrad bf16
 pmc fwd32s enc1.conv0 fwd fp32
 pmc dgrad32s enc1.conv0 dgrad fp32
 pmc wgrad_strided enc1.conv0 wgrad fp32
