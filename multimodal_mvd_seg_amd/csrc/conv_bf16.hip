@@ -1836,6 +1836,9 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
         // waves; at 64^3 (>= 1024 workgroups) the two co-resident four-wave workgroups overlap better: 0.161 vs 0.160 forward,
         // 0.150 vs 0.142 input gradient -- so only where a CU gets at most a few tiles
         if (tg.magHW >= 0 && tg.magW >= 0 && wgs8 >= 256 && wgs8 < 1024) {
+            // (round 3: eight instead of four taps per weight group -- on the idea that a group's 16 KB of weights arrive from
+            // L2 later than its 32 MFMAs per wave retire -- measured no different: 0.070 vs 0.069 ms on 128 -> 128 @32^3, 37 %
+            // MFMA-busy either way)
             int r = launch_fwd16<2, 2, 4, 8, false, 8>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
             if (r >= 0) return r;
         }
