@@ -190,9 +190,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
     long long *stamps = reinterpret_cast<long long *>(part);  // diagnostic build only: in-kernel s_memtime stamps of one wave
     int nst = 0;
 #endif
-    const int rot = item % ngroups;
-    const bool fullg = ngroups * TG == g.ntaps;  // every group has TG taps (27 taps, TG = 3): no per-slot tap tests
-    for (int cc = cc_begin; cc < cc_end; cc++) {
+    // halo of one 32-channel chunk into registers (XR x 16 bytes per thread)
+    constexpr bool PREF = NW == 8;
+    uint4 hv[XR];
+    auto load_halo = [&](int cc) {
         const int c0 = cc * 32;
         const unsigned short *src;
         int Cs, cofs;
@@ -201,43 +202,50 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
         } else {
             src = a2; Cs = g.C2; cofs = c0 - g.C1;
         }
-        load_w(cc, rot, wrA);
-        if (ngroups > 1) load_w(cc, (rot + 1) % ngroups, wrB);
-        __syncthreads();  // B1: every wave is done with the previous chunk's LDS
-        {
-            uint4 v[XR];
 #pragma unroll
-            for (int u = 0; u < XR; u++) {
-                const int idx = u * TPB + tid;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (idx < nx) {
-                    const int slot = idx >> 2;
-                    const int ez = (slot * tg.magHW) >> 20, rem = slot - ez * EHW;
-                    const int ey = (rem * tg.magW) >> 20, ex = rem - ey * tg.EW;
-                    const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
-                    if (!(MVD_F16_DBG & 16) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
-                        v[u] = *reinterpret_cast<const uint4 *>(
-                            src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid & 3) * 8);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < XR; u++) {
-                const int idx = u * TPB + tid;
-                int part = idx & 3;
-                if (SWZ) {
-                    const int slot = idx >> 2;
-                    const int ez = (slot * tg.magHW) >> 20, rem = slot - ez * EHW;
-                    part ^= ((rem * tg.magW) >> 20) & 3;  // halo y-row of the slot
-                }
-                *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * XS + part * 16) = v[u];
+        for (int u = 0; u < XR; u++) {
+            const int idx = u * TPB + tid;
+            hv[u] = make_uint4(0, 0, 0, 0);
+            if (idx < nx) {
+                const int slot = idx >> 2;
+                const int ez = (slot * tg.magHW) >> 20, rem = slot - ez * EHW;
+                const int ey = (rem * tg.magW) >> 20, ex = rem - ey * tg.EW;
+                const int id = iz0 + ez, ih = iy0 + ey, iw = ix0 + ex;
+                if (!(MVD_F16_DBG & 16) && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                    hv[u] = *reinterpret_cast<const uint4 *>(
+                        src + ((((size_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * Cs + cofs + (tid & 3) * 8);
             }
         }
+    };
+    const int rot = item % ngroups;
+    const bool fullg = ngroups * TG == g.ntaps;  // every group has TG taps (27 taps, TG = 3): no per-slot tap tests
+    for (int cc = cc_begin; cc < cc_end; cc++) {
+        load_w(cc, rot, wrA);
+        if (ngroups > 1) load_w(cc, (rot + 1) % ngroups, wrB);
+        if (!PREF || cc == cc_begin) load_halo(cc);
+        __syncthreads();  // B1: every wave is done with the previous chunk's LDS
+#pragma unroll
+        for (int u = 0; u < XR; u++) {
+            const int idx = u * TPB + tid;
+            int part = idx & 3;
+            if (SWZ) {
+                const int slot = idx >> 2;
+                const int ez = (slot * tg.magHW) >> 20, rem = slot - ez * EHW;
+                part ^= ((rem * tg.magW) >> 20) & 3;  // halo y-row of the slot
+            }
+            *reinterpret_cast<uint4 *>(Xs + (size_t)(idx >> 2) * XS + part * 16) = hv[u];
+        }
+        // PREF (one workgroup per CU: nothing else hides the fetch): the next chunk's halo travels while this chunk's 27 taps run
+        if (PREF && cc + 1 < cc_end) load_halo(cc + 1);
         auto group_mfmas = [&](int gi, int wbuf) __attribute__((always_inline)) {
             const unsigned char *wb_ = Wsm + (size_t)wbuf * WBUF;
             // operand registers are double buffered over the 2*TG (tap, k-step) slots of the group: the fragments of
             // slot j+1 are read from LDS before slot j's MFMAs are issued, so a register an in-flight MFMA still reads
             // is never the target of the next ds_read (tools/probes/mfma_probe.hip: 111 -> 137 TFLOP/s effect)
-            bf16x8 af[2][MT], bfr[2][NT];
+            // RA = read-ahead in (tap, k-step) slots.  (Round 3: RA = 2 on the eight-wave form -- a slot is only four MFMAs per
+            // wave -- measured SLOWER: 128 -> 128 @32^3 0.070 -> 0.071, 256 -> 128 0.118 -> 0.125 ms.)
+            constexpr int RA = 1, NBUF = RA + 1;
+            bf16x8 af[NBUF][MT], bfr[NBUF][NT];
             int to3[TG];
 #pragma unroll
             for (int tl = 0; tl < TG; tl++) to3[tl] = __builtin_amdgcn_readlane(toff_l, gi * TG + tl);
@@ -260,20 +268,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void k_fwd16(const FwdGeo
 #if (MVD_F16_DBG & 4)
             if (gi == 0)
 #endif
-            read_ops(0, 0);
+            {
+#pragma unroll
+                for (int j = 0; j < RA && j < 2 * TG; j++) read_ops(j, j % NBUF);
+            }
 #pragma unroll
             for (int j = 0; j < 2 * TG; j++) {
 #if (MVD_F16_DBG & 4)
                 if (gi == 0)
 #endif
-                if (j + 1 < 2 * TG) read_ops(j + 1, (j + 1) & 1);
+                if (j + RA < 2 * TG) read_ops(j + RA, (j + RA) % NBUF);
 #if !(MVD_F16_DBG & 2)
                 if (fullg || gi * TG + (j >> 1) < g.ntaps) {  // block-uniform
 #pragma unroll
                     for (int m = 0; m < MT; m++)
 #pragma unroll
                         for (int q_ = 0; q_ < NT; q_++)
-                            acc[m][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j & 1][q_], af[j & 1][m], acc[m][q_], 0, 0, 0);
+                            acc[m][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j % NBUF][q_], af[j % NBUF][m], acc[m][q_], 0, 0, 0);
                 }
 #endif
             }
@@ -1839,7 +1850,9 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
             // (round 3: eight instead of four taps per weight group -- on the idea that a group's 16 KB of weights arrive from
             // L2 later than its 32 MFMAs per wave retire -- measured no different: 0.070 vs 0.069 ms on 128 -> 128 @32^3, 37 %
             // MFMA-busy either way)
-            int r = launch_fwd16<2, 2, 4, 8, false, 8>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
+            static const int w8swz = getenv("MVD_FWD16_W8SWZ") ? atoi(getenv("MVD_FWD16_W8SWZ")) : 0;
+            int r = w8swz ? launch_fwd16<2, 2, 4, 8, true, 8>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s)
+                          : launch_fwd16<2, 2, 4, 8, false, 8>(g, tg, a1, a2, w, bias, y1, y2, ws, ws_bytes, s);
             if (r >= 0) return r;
         }
     }
