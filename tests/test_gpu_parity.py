@@ -630,6 +630,40 @@ def test_packed_weight_cache_sees_every_torch_visible_write_and_guards_saved_pac
     assert xg.grad is not None
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pack_cache_is_scoped_per_optimizer(precision):
+    """another optimizer's step() must neither re-pack nor invalidate THIS optimizer's weights -- an autograd
+    graph kept across it back-propagates (its packs are untouched), its packed copies stay valid, and the stepping
+    optimizer's own graph is still guarded."""
+    from multimodal_mvd_seg_amd import network, ops, optim
+    torch.manual_seed(1)
+    ca = network.HipConv3d(32, 32, 3, 1, padding=1, bias=True).to(DEV)
+    cb = network.HipConv3d(32, 32, 3, 1, padding=1, bias=True).to(DEV)
+    fa, fb = optim.FlatParams(list(ca.parameters())), optim.FlatParams(list(cb.parameters()))
+    oa, ob = optim.FusedSGDNesterov(fa, 1e-2), optim.FusedSGDNesterov(fb, 1e-2)
+    x = torch.randn(1, 32, 8, 8, 16, device=DEV)
+    if precision == "bf16":
+        ca.precision = cb.precision = "bf16"
+        x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last_3d)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = ca(xa), cb(xb)
+    ref = torch.autograd.grad(ca(xa), xa, torch.ones_like(ya))[0]
+    ob.zero_grad()
+    fb.grad.normal_()
+    ob.step()                                  # B steps while A's graph is alive
+    ya.backward(torch.ones_like(ya))           # ... A's graph is untouched: no "weights were updated", same gradient
+    assert torch.equal(xa.grad, ref)
+    if precision == "fp32":                    # B's own graph is guarded as before (fp32 packs are rebuilt in place; the bf16
+        with pytest.raises(RuntimeError, match="weights were updated"):   # packs of an eager run are fresh buffers per step)
+            yb.backward(torch.ones_like(yb))
+    with torch.no_grad():                      # and A's packed copies are still the ones of A's (unchanged) weights
+        c2 = network.HipConv3d(32, 32, 3, 1, padding=1, bias=True).to(DEV)
+        c2.load_state_dict(ca.state_dict())
+        if precision == "bf16":
+            c2.precision = "bf16"
+        assert torch.equal(ca(x), c2(x))
+
+
 # ================================================================================================ end to end
 def _mi355_net_from_fixture(z, in_ch, n_stages):
     from multimodal_mvd_seg_amd import network
