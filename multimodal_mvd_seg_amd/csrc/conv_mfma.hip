@@ -2684,44 +2684,67 @@ __global__ __launch_bounds__(256, 2) void k_wgrad16(const WgradGeom g, const WgT
 // the four group sums are combined in a fixed order through LDS.
 // Blocks past the weight elements (nbias_blocks of them, optional) reduce the bias-gradient rows pbias[row][K] the same
 // way -- one launch instead of two per layer (the separate k_dbias_reduce launch cost ~5.5 us for 32-320 sums).
-__global__ __launch_bounds__(256) void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial,
-                                                        float *__restrict__ dw, int nsplit, const float *__restrict__ pbias,
-                                                        float *__restrict__ dbias, int nrows, int wblocks) {
-    __shared__ double red[4][64];
+// G = split groups per block (threads = 64 G).  Round 3: with 4 groups a thread walked nsplit / 4 partials, four loads in
+// flight -- 16 serial L2 round trips for the 256 partial sets of a 128^3 layer, on a grid of only 27 C K / 64 blocks (432 for
+// 32 x 32 channels): 11-22 us per launch, 0.53 ms per bf16 step in 27 launches.  16 groups: four round trips.
+template <int G>
+__global__ __launch_bounds__(64 * G) void k_wgrad_reduce_f(WgradGeom g, const float *__restrict__ partial,
+                                                           float *__restrict__ dw, int nsplit, const float *__restrict__ pbias,
+                                                           float *__restrict__ dbias, int nrows, int wblocks) {
+    __shared__ double red[G][64];
     const int C = g.C1 + g.C2, K = g.K;
     const long per = (long)g.ntaps * C * K;
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    auto combine = [&]() {  // fixed order: pairs, then pairs of pairs ...
+        double t[G];
+#pragma unroll
+        for (int i = 0; i < G; i++) t[i] = red[i][e];
+#pragma unroll
+        for (int w = 1; w < G; w *= 2)
+#pragma unroll
+            for (int i = 0; i + w < G; i += 2 * w) t[i] += t[i + w];
+        return t[0];
+    };
     if (pbias && (int)blockIdx.x >= wblocks) {  // block-uniform
         const int k = ((int)blockIdx.x - wblocks) * 64 + e;
         double s = 0;
         if (k < K)
-            for (int r = q; r < nrows; r += 4) s += (double)pbias[(size_t)r * K + k];
+            for (int r = q; r < nrows; r += G) s += (double)pbias[(size_t)r * K + k];
         red[q][e] = s;
         __syncthreads();
-        if (q == 0 && k < K) dbias[k] = (float)((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+        if (q == 0 && k < K) dbias[k] = (float)combine();
         return;
     }
     const long j = (long)blockIdx.x * 64 + e;
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (j < per) {
         int b = q;
-        for (; b + 12 < nsplit; b += 16) {
+        for (; b + 3 * G < nsplit; b += 4 * G) {
             s0 += (double)partial[(size_t)b * per + j];
-            s1 += (double)partial[(size_t)(b + 4) * per + j];
-            s2 += (double)partial[(size_t)(b + 8) * per + j];
-            s3 += (double)partial[(size_t)(b + 12) * per + j];
+            s1 += (double)partial[(size_t)(b + G) * per + j];
+            s2 += (double)partial[(size_t)(b + 2 * G) * per + j];
+            s3 += (double)partial[(size_t)(b + 3 * G) * per + j];
         }
-        for (; b < nsplit; b += 4) s0 += (double)partial[(size_t)b * per + j];
+        for (; b < nsplit; b += G) s0 += (double)partial[(size_t)b * per + j];
     }
     red[q][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (q != 0 || j >= per) return;
-    const double s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    const double s = combine();
     const int k = (int)(j % K);
     const int c = (int)((j / K) % C);
     const int t = g.wt[(int)(j / ((long)K * C))];
     size_t o = g.transposed_out ? ((size_t)c * K + k) * g.T + t : ((size_t)k * C + c) * g.T + t;
     dw[o] = (float)s;
+}
+
+static void launch_wgrad_reduce_f(unsigned blocks, hipStream_t s, const WgradGeom &g, const float *partial, float *dw, int nsplit,
+                                  const float *pbias, float *dbias, int nrows, int wblocks) {
+    static const int g16 = getenv("MVD_WGRAD_REDUCE_G16") ? atoi(getenv("MVD_WGRAD_REDUCE_G16")) : 1;
+    if (g16 && nsplit >= 64)
+        hipLaunchKernelGGL(k_wgrad_reduce_f<16>, dim3(blocks), dim3(1024), 0, s, g, partial, dw, nsplit, pbias, dbias, nrows, wblocks);
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce_f<4>, dim3(blocks), dim3(256), 0, s, g, partial, dw, nsplit, pbias, dbias, nrows, wblocks);
 }
 
 static int wgrad_max_split(const WgradGeom &g, int per_cu = 2) {
@@ -2766,11 +2789,11 @@ int wgrad16z_run(const WgradGeom &g, const unsigned short *a1, const unsigned sh
     float *partial_z = reinterpret_cast<float *>(ws);
     const int wblocks = (int)cdiv((long)27 * C * g.K, 64);
     if (pbias_z) {
-        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks + cdiv(g.K, 64)), dim3(256), 0, s, g, partial_z, dw, nsplit_z, pbias_z, dbias,
+        launch_wgrad_reduce_f((unsigned)(wblocks + cdiv(g.K, 64)), s, g, partial_z, dw, nsplit_z, pbias_z, dbias,
                            nsplit_z, wblocks);
         *dbias_done = 1;
     } else {
-        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks), dim3(256), 0, s, g, partial_z, dw, nsplit_z, (const float *)nullptr,
+        launch_wgrad_reduce_f((unsigned)(wblocks), s, g, partial_z, dw, nsplit_z, (const float *)nullptr,
                            (float *)nullptr, 0, 0);
     }
     return check_launch("conv wgrad reduce (bf16 z-marching)");
@@ -2973,11 +2996,11 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         const long per16 = (long)g.ntaps * C * g.K;
         const int wblocks = (int)cdiv(per16, 64);
         if (pbias16) {  // the bias rows ride in the same reduce launch
-            hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks + cdiv(g.K, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit, pbias16,
+            launch_wgrad_reduce_f((unsigned)(wblocks + cdiv(g.K, 64)), s, g, partial, dw, tg.nsplit, pbias16,
                                dbias, tg.nsplit, wblocks);
             *dbias_done = 1;
         } else {
-            hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks), dim3(256), 0, s, g, partial, dw, tg.nsplit, (const float *)nullptr,
+            launch_wgrad_reduce_f((unsigned)(wblocks), s, g, partial, dw, tg.nsplit, (const float *)nullptr,
                                (float *)nullptr, 0, 0);
         }
         return check_launch("conv wgrad reduce (bf16 mfma)");
@@ -3056,7 +3079,7 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
         hipLaunchKernelGGL(kern, dim3(tg.nsplit, tg.nkb), dim3(256), lds2, s, g, tg, a1, b, partial);
         if (check_launch("conv wgrad (mfma, narrow input)")) return 1;
         const long per2 = (long)g.ntaps * C * g.K;
-        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(cdiv(per2, 64)), dim3(256), 0, s, g, partial, dw, tg.nsplit, (const float *)nullptr,
+        launch_wgrad_reduce_f((unsigned)(cdiv(per2, 64)), s, g, partial, dw, tg.nsplit, (const float *)nullptr,
                            (float *)nullptr, 0, 0);
         return check_launch("conv wgrad reduce (mfma)");
     }
@@ -3090,11 +3113,11 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
     const long per = (long)g.ntaps * C * g.K;
     const int wblocks = (int)cdiv(per, 64);
     if (pbias_g) {  // the bias rows ride in the same reduce launch
-        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks + cdiv(g.K, 64)), dim3(256), 0, s, g, partial, dw, 2 * tg.nsplit,
+        launch_wgrad_reduce_f((unsigned)(wblocks + cdiv(g.K, 64)), s, g, partial, dw, 2 * tg.nsplit,
                            (const float *)pbias_g, dbias, tg.nsplit * 4, wblocks);
         *dbias_done = 1;
     } else {
-        hipLaunchKernelGGL(k_wgrad_reduce_f, dim3(wblocks), dim3(256), 0, s, g, partial, dw, 2 * tg.nsplit, (const float *)nullptr,
+        launch_wgrad_reduce_f((unsigned)(wblocks), s, g, partial, dw, 2 * tg.nsplit, (const float *)nullptr,
                            (float *)nullptr, 0, 0);
     }
     return check_launch("conv wgrad reduce (mfma)");
