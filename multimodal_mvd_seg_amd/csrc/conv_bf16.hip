@@ -1785,9 +1785,10 @@ int fwd_bf16_stats_tiles(const FwdGeom &g) {
 int fwd_bf16_prologue_ok(const FwdGeom &g) {  // 1: the shape runs on a kernel with the InstanceNorm input prologue
     int nt = 0;
     if ((g.C1 + g.C2) % 32 || (g.K1 + g.K2) % 32 || (g.K2 != 0)) return 0;
-    if (g.C1 == 32 && g.C2 == 0 &&
+    if ((g.C1 == 32 || g.C1 == 64) && g.C2 == 0 &&  // one producer tensor of 32 or 64 channels (k_fwd16y, one or two chunks)
         launch_fwd16y(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (num_cus16() / 8) * 8, &nt) == 0)
         return 1;
+    if (g.C1 != 32 || g.C2 != 0) return 0;
     return launch_fwd16p(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &nt) == 0 ? 1 : 0;
 }
 

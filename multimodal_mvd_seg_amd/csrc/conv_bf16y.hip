@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
                                                    float *__restrict__ tile_stats, const float *__restrict__ in_scale,
                                                    const float *__restrict__ in_shift, const float slope) {
     constexpr bool ST = (FUSE & 1) != 0, PRO = (FUSE & 2) != 0;
-    static_assert(!(PRO && NCH != 1), "the loader prologue normalises ONE 32-channel producer");
+    // (PRO with NCH = 2: the producer is ONE 64-channel tensor, chunk c = its channels 32 c .. 32 c + 31 -- host-checked)
     constexpr int RG = 4 / KQ;                                    // row groups of four output rows
     constexpr int Y_PARTS = y_parts(KQ), Y_XR = y_xr(KQ), Y_CHUNK = y_chunk(KQ), OB = 32 * KQ;  // OB: bytes per output voxel
     constexpr int IMG = NCH * Y_CHUNK;   // bytes of a plane image (all chunks)
@@ -160,13 +160,17 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
     float bq[4];  // bias of this lane's 4 channels (D rows 4 kq + e of the wave's 16)
 #pragma unroll
     for (int e = 0; e < 4; e++) bq[e] = bias ? bias[tg.koff + 16 * kh + 4 * kq + e] : 0.f;
-    float psc[PRO ? 8 : 1], psh[PRO ? 8 : 1];  // PRO: scale / shift of the staged channel octet (part tid & 3)
-    if (PRO) {
-        const float *sp = in_scale + (size_t)n_ * 32 + (tid & 3) * 8, *tp = in_shift + (size_t)n_ * 32 + (tid & 3) * 8;
+    float psc[PRO ? NCH : 1][PRO ? 8 : 1], psh[PRO ? NCH : 1][PRO ? 8 : 1];  // PRO: scale / shift of the staged channel octets
+    if (PRO) {                                                                // (part tid & 3 of every chunk)
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            psc[e] = sp[e];
-            psh[e] = tp[e];
+        for (int c = 0; c < NCH; c++) {
+            const float *sp = in_scale + (size_t)n_ * 32 * NCH + c * 32 + (tid & 3) * 8;
+            const float *tp = in_shift + (size_t)n_ * 32 * NCH + c * 32 + (tid & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                psc[c][e] = sp[e];
+                psh[c][e] = tp[e];
+            }
         }
     }
     float ssum[ST ? 4 : 1], ssq[ST ? 4 : 1];  // ST: running sums of this lane's 4 channels over its voxels
@@ -194,14 +198,15 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
                                                        live(j) ? (int)iplane32 : 0, 0x00020000);
     };
     auto stage_load = [&](int set, int c, int u) { v[set][c][u] = __builtin_amdgcn_raw_buffer_load_b128(rin[c], (int)rel[u], 0, 0); };
-    auto prologue = [&](u32x4y q, int u, bool lv) {
+    auto prologue = [&](u32x4y q, int u, bool lv, int c) {
         const bool ok = lv && rel[u] != 0xfffffff0u;
         unsigned d[4] = {q.x, q.y, q.z, q.w};
+        const int cp = PRO ? c : 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             float lo = __uint_as_float(d[e] << 16), hi = __uint_as_float(d[e] & 0xffff0000u);
-            lo = __builtin_fmaf(lo, psc[2 * e], psh[2 * e]);
-            hi = __builtin_fmaf(hi, psc[2 * e + 1], psh[2 * e + 1]);
+            lo = __builtin_fmaf(lo, psc[cp][2 * e], psh[cp][2 * e]);
+            hi = __builtin_fmaf(hi, psc[cp][2 * e + 1], psh[cp][2 * e + 1]);
             lo = fmaxf(lo, lo * slope);
             hi = fmaxf(hi, hi * slope);
             d[e] = ok ? cvt_pk_bf16y(lo, hi) : 0u;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void k_fwd16y(const FwdGeom g, const Fwd16Y
         return u32x4y{d[0], d[1], d[2], d[3]};
     };
     auto stage_write = [&](int set, int c, unsigned imgoff, int u, bool lv) {
-        const u32x4y q = PRO ? prologue(v[set][c][u], u, lv) : v[set][c][u];
+        const u32x4y q = PRO ? prologue(v[set][c][u], u, lv, c) : v[set][c][u];
         if (u < Y_XR - 1 || tid < Y_PARTS - (Y_XR - 1) * 256) *(lds_u4y *)(wa[u] + imgoff + c * Y_CHUNK) = q;
     };
     auto load_plane = [&](int set, int j) {
@@ -435,14 +440,14 @@ int launch_fwd16y(const FwdGeom &g, const unsigned short *a1, const unsigned sho
     }
     const bool want_stats = fuse && fuse->tile_stats && stats_ok;
     const bool want_pro = fuse && fuse->in_scale && fuse->in_shift;
-    if (want_pro && (nch != 1 || two_out)) return -1;
+    if (want_pro && (two_out || (nch == 2 && vstride != 128))) return -1;  // one producer tensor of 32 or 64 channels
     if (fuse && fuse->ntiles) *fuse->ntiles = want_stats ? tz.nzc * tz.nty * tz.ntx : 0;
     typedef void (*ky_t)(const FwdGeom, const Fwd16YTile, const unsigned short *, const unsigned short *, const unsigned short *,
                          const float *, unsigned short *, float *, const float *, const float *, const float);
     static const ky_t kern[2][2][4] = {{{k_fwd16y<1, 0, 2>, k_fwd16y<1, 1, 2>, k_fwd16y<1, 2, 2>, k_fwd16y<1, 3, 2>},
-                                        {k_fwd16y<2, 0, 2>, k_fwd16y<2, 1, 2>, nullptr, nullptr}},
+                                        {k_fwd16y<2, 0, 2>, k_fwd16y<2, 1, 2>, k_fwd16y<2, 2, 2>, k_fwd16y<2, 3, 2>}},
                                        {{k_fwd16y<1, 0, 4>, k_fwd16y<1, 1, 4>, k_fwd16y<1, 2, 4>, k_fwd16y<1, 3, 4>},
-                                        {k_fwd16y<2, 0, 4>, k_fwd16y<2, 1, 4>, nullptr, nullptr}}};
+                                        {k_fwd16y<2, 0, 4>, k_fwd16y<2, 1, 4>, k_fwd16y<2, 2, 4>, k_fwd16y<2, 3, 4>}}};
     const int fz = (want_stats ? 1 : 0) | (want_pro ? 2 : 0), ki = KQ == 2 ? 0 : 1;
     const ky_t kfn = kern[ki][nch - 1][fz];
     const size_t lds = 2 * (size_t)nch * (KQ == 2 ? y_chunk(2) : y_chunk(4));

@@ -178,6 +178,8 @@ class StackedConvBlocks(nn.Module):
         shape = (inp.shape[0], sp[0], sp[1], sp[2], blk.output_channels, 0, w.shape[0], ops.i3((3, 3, 3)), ops.i3((1, 1, 1)))
         if ops.query("mvd_conv3d_fwd_bf16_prologue_ok", *shape) <= 0:
             return False
+        if blk.output_channels > 32 and os.environ.get("MVD_FUSE_PROLOGUE_C64", "1") == "0":   # (A/B: the 64-channel blocks)
+            return False
         if train and mode not in ("1", "true"):   # "auto": only where the weight gradient has the prologue too
             return ops.WGRAD_PROLOGUE and ops.query("mvd_conv3d_wgrad_bf16_prologue_ok", *shape) > 0
         return True

@@ -509,3 +509,32 @@ def test_train_step_with_the_fused_block_in_training_is_bit_identical_to_the_unf
     for p, q in zip(res[0][1], res[1][1]):
         assert torch.equal(p, q)
     assert counts["auto"] >= 2 and counts["0"] == 0, counts   # the fused weight gradient really ran (once per step) in "auto"
+
+
+@pytest.mark.parametrize("K,N,D,H,W", [(64, 2, 64, 64, 64), (64, 2, 52, 60, 44), (32, 1, 65, 70, 97)])
+def test_loader_prologue_of_a_64_channel_producer_bit_for_bit(K, N, D, H, W):
+    """The 64^3 stage (enc1 / dec4 of configs[1]): the producing conv has 64 channels, i.e. TWO 32-channel chunks in the
+    consumer's loader, each with its own scale / shift octets.  conv(lrelu(IN(y0))) through the apply pass + plain conv ==
+    the fused conv reading y0, bit for bit (ragged volumes: padding is zero in the ACTIVATION)."""
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    C = 64
+    g = torch.Generator().manual_seed(3 * D + K)
+    y0 = (torch.randn(N, C, D, H, W, generator=g) * 1.5 + 0.3).to(BF).to(DEV).contiguous(memory_format=CL)
+    w = (torch.randn(K, C, 3, 3, 3, generator=g) / np.sqrt(27 * C)).to(DEV)
+    b = (torch.randn(K, generator=g) * 0.1).to(DEV)
+    scale = (torch.rand(N, C, generator=g) + 0.3).to(DEV)
+    shift = (torch.randn(N, C, generator=g) * 0.5 + 0.4).to(DEV)
+    assert query("mvd_conv3d_fwd_bf16_prologue_ok", N, D, H, W, C, 0, K, i3((3, 3, 3)), i3((1, 1, 1))) == 1
+    a0 = torch.empty_like(y0)
+    call("mvd_instnorm_lrelu_apply_bf16", _p(y0), _p(scale), _p(shift), _p(a0), N, D * H * W, C, 0.01, _stream())
+    y_ref, _s, _g, _n = _conv_fused(a0, w, b, want_stats=False)
+    y_fused, stats, got, nt = _conv_fused(y0, w, b, scale, shift, 0.01, want_stats=True)
+    assert torch.equal(y_fused, y_ref), f"{int((y_fused != y_ref).sum())} differ"
+    if nt > 0:
+        assert got == nt
+        yd = y_fused.permute(0, 2, 3, 4, 1).reshape(N, -1, K).double()
+        tol_s, tol_q = _sum_tolerances(yd)
+        assert bool(((stats.double().sum(1)[..., 0] - yd.sum(1)).abs() <= tol_s).all())
+        assert bool(((stats.double().sum(1)[..., 1] - (yd * yd).sum(1)).abs() <= tol_q).all())
+    # two producer TENSORS (the decoder's concatenation) have no single InstanceNorm in front: refused
+    assert query("mvd_conv3d_fwd_bf16_prologue_ok", N, D, H, W, 32, 32, K, i3((3, 3, 3)), i3((1, 1, 1))) == 0
