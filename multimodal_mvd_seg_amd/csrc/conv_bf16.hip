@@ -561,6 +561,10 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16s(const FwdGeom g, const Dg16
     }
 }
 
+// (Round 3, tried: a persistent form for K <= 64 -- one workgroup per CU walking tiles, the wave's class weights resident in
+// 128 registers, the next tile's dy prefetched into registers: 64 -> 32 at 128^3 0.189 -> 0.179 ms, nothing inside the step.
+// The launch is bound by one memory round trip per 49 KB tile with two tiles in flight per CU either way, not by the
+// weights' L2 latency; more tiles in flight do not fit beside resident weights.  Not kept.)
 int dgrad16s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const unsigned short *dy, const unsigned short *wb,
              unsigned short *dx, hipStream_t s, int accumulate) {
     static const int on = getenv("MVD_DGRAD16S") ? atoi(getenv("MVD_DGRAD16S")) : 1;
