@@ -59,3 +59,34 @@ def test_ops_refuse_cpu_tensors():
     from multimodal_mvd_seg_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.to_ndhwc(torch.zeros(1, 2, 3, 3, 3))
+
+
+@pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason="libmvdseg_hip.so not built (run __graft_entry__.build())")
+def test_shape_queries_and_selector_errors_are_host_logic():
+    """The eligibility queries of the fused block (round 3) are pure host arithmetic -- what network.StackedConvBlocks asks
+    before anything runs -- and the kernel selectors reject bad values with an error message (no compute call here)."""
+    from multimodal_mvd_seg_amd._lib import i3
+    lib = _lib.load()
+    k3, s1, s2 = i3((3, 3, 3)), i3((1, 1, 1)), i3((2, 2, 2))
+    # weight-gradient loader prologue (k_wgrad16z): plain 3x3x3 stride 1, ONE producer tensor, channels in blocks of 32, W >= 32
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(2, 128, 128, 128, 32, 0, 32, k3, s1) == 1
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(2, 64, 64, 64, 64, 0, 64, k3, s1) == 1
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(1, 9, 8, 32, 32, 0, 64, k3, s1) == 1
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(2, 128, 128, 16, 32, 0, 32, k3, s1) == 0     # narrower than a column
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(2, 128, 128, 128, 32, 32, 32, k3, s1) == 0   # two producer tensors
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(2, 128, 128, 128, 32, 0, 64, k3, s2) == 0    # strided
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(2, 128, 128, 128, 24, 0, 32, k3, s1) == 0    # not a multiple of 32 channels
+    assert lib.mvd_conv3d_wgrad_bf16_prologue_ok(0, 128, 128, 128, 32, 0, 32, k3, s1) == 0    # empty batch
+    # forward loader prologue (k_fwd16y): one producer tensor of 32 or 64 channels on a large volume
+    assert lib.mvd_conv3d_fwd_bf16_prologue_ok(2, 128, 128, 128, 32, 0, 32, k3, s1) == 1
+    assert lib.mvd_conv3d_fwd_bf16_prologue_ok(2, 64, 64, 64, 64, 0, 64, k3, s1) == 1
+    assert lib.mvd_conv3d_fwd_bf16_prologue_ok(2, 128, 128, 128, 32, 32, 32, k3, s1) == 0
+    assert lib.mvd_conv3d_fwd_bf16_prologue_ok(2, 128, 128, 128, 32, 0, 64, k3, s2) == 0
+    assert lib.mvd_conv3d_fwd_bf16_prologue_ok(2, 8, 8, 8, 32, 0, 32, k3, s1) == 0            # too few tiles for the kernel
+    # statistics epilogue: tiles per sample of the kernel that would run, 0 when it has none
+    assert lib.mvd_conv3d_fwd_bf16_stats_tiles(2, 128, 128, 128, 32, 0, 32, k3, s1) > 0
+    assert lib.mvd_conv3d_fwd_bf16_stats_tiles(2, 8, 8, 8, 320, 0, 320, k3, s1) == 0
+    # selectors
+    for fn, bad in ((lib.mvd_set_bf16_wgrad_kernel, 5), (lib.mvd_set_bf16_zmarch_kernel, 7)):
+        assert fn(bad) == 2 and len(lib.mvd_last_error()) > 10
+        assert fn(1) == 0
