@@ -1816,6 +1816,10 @@ int fwd_bf16(const FwdGeom &g, const unsigned short *a1, const unsigned short *a
         if (r >= 0) return r;
         r = launch_fwd16p(g, a1, w, bias, y1, y2, s, fuse);
         if (r >= 0) return r;
+        if (!fuse || (!fuse->in_scale && !fuse->tile_stats)) {
+            r = launch_fwd16ys(g, a1, a2, w, bias, y1, y2, s, (num_cus16() / 8) * 8);
+            if (r >= 0) return r;
+        }
     }
     if (fuse && fuse->in_scale) return -1;  // the generic kernels have no input prologue
     const int NT = (K % 64 == 0) ? 2 : 1;

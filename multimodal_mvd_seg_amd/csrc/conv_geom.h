@@ -86,6 +86,9 @@ int dgrad32s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, c
 // bf16 twin (conv_bf16.hip): all eight parity classes of a 3x3x3 stride-2 conv's input gradient from one staged dy tile
 int dgrad16s(int N, int D, int H, int W, int C, int K, int Do, int Ho, int Wo, const unsigned short *dy, const unsigned short *wb,
              unsigned short *dx, hipStream_t s, int accumulate = 0);
+// bf16 z-marching stride-2 forward conv 32 -> 64 channels (conv_bf16s.hip): -1 = not this kernel's shape
+int launch_fwd16ys(const FwdGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *w, const float *bias,
+                   unsigned short *y1, unsigned short *y2, hipStream_t s, int ncu);
 // bf16 z-marching weight gradient of the plain 3x3x3 stride-1 conv (conv_bf16w.hip): -1 = not this kernel's problem, 0 = the
 // partials [nsplit][27][C][K] (and, if asked, bias rows [nsplit][K] at *pbias_out) are in ws
 int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,

@@ -538,3 +538,27 @@ def test_loader_prologue_of_a_64_channel_producer_bit_for_bit(K, N, D, H, W):
         assert bool(((stats.double().sum(1)[..., 1] - (yd * yd).sum(1)).abs() <= tol_q).all())
     # two producer TENSORS (the decoder's concatenation) have no single InstanceNorm in front: refused
     assert query("mvd_conv3d_fwd_bf16_prologue_ok", N, D, H, W, 32, 32, K, i3((3, 3, 3)), i3((1, 1, 1))) == 0
+
+
+@pytest.mark.parametrize("N,D,H,W", [(2, 128, 128, 128), (1, 131, 127, 129), (1, 96, 200, 64)])
+def test_fwd16ys_stride2_forward_exact_integer_data(N, D, H, W):
+    """k_fwd16ys (z-marching stride-2 conv 32 -> 64, parity-split LDS image) on small-integer data: every product and fp32
+    partial sum is exact, so the output must equal torch's exact fp32 convolution rounded once to bf16, bit for bit -- even
+    and odd input extents (the last input plane / row / column may or may not exist), several z chunks per column; the generic
+    kernel on the same data must agree (mvd_set_bf16_zmarch_kernel(0) switches the z-marching kernels off)."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(D + 3 * W)
+    ints = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=g).float()
+    x, w, b = ints((N, 32, D, H, W), -2, 2), ints((64, 32, 3, 3, 3), -2, 2), ints((64,), -3, 3)
+    ref = F.conv3d(x, w, b, 2, 1).to(BF)
+    outs = []
+    for which in (1, 0):
+        _set_kernel(which)
+        try:
+            with torch.no_grad():
+                y = ops.Conv3dFn.apply(x.to(DEV).to(BF).contiguous(memory_format=CL), None, w.to(DEV), b.to(DEV), (2, 2, 2))
+        finally:
+            _set_kernel(1)
+        assert torch.equal(y.cpu(), ref), f"kernel {which}: {int((y.cpu() != ref).sum())} of {ref.numel()} differ"
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
