@@ -84,12 +84,16 @@ __device__ inline u32x4z wz_rsrc(const char *base, bool ok) {
 }
 template <int N, int CNT>
 __device__ inline void wz_wait(u32x4z (&r)[CNT]) {  // s_waitcnt vmcnt(N); the staged registers are only valid behind it
-    static_assert(CNT == 2 || CNT == 3 || CNT == 4 || CNT == 6, "staging set sizes");
+    static_assert(CNT == 2 || CNT == 3 || CNT == 4 || CNT == 6 || CNT == 10, "staging set sizes");
     if constexpr (CNT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N));
     if constexpr (CNT == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) : "n"(N));
     if constexpr (CNT == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
     if constexpr (CNT == 6)
         asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(N));
+    if constexpr (CNT == 10)
+        asm volatile("s_waitcnt vmcnt(%10)"
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9])
+                     : "n"(N));
 }
 
 // NG = wave groups of the workgroup (4 waves each).  NG = 2: eight waves, two per SIMD -- group g takes the output rows
@@ -441,6 +445,239 @@ __global__ __launch_bounds__(256 * NG, 1) void k_wgrad16z(const WgradGeom g, con
     if (ones_slot && pbias != nullptr && cb == 0 && h == 0) pbias[(size_t)split * K + k0 + i] = acc[6][0];
 }
 
+// ------------------------------------------------------------------------------------------------ stride 2
+// k_wgrad16zs (round 3): the same z-marching weight gradient for 3x3x3 STRIDE-2 convs (first conv of encoder stages 1, 2):
+// dw[tap][c][k] = sum over OUTPUT voxels o of x[2 o + tap - 1][c] dy[o][k].  The tiled kernel (k_wgrad16<7,7,2,1,false>) needed
+// 0.198 ms for 32 -> 64 at 128^3 -> 64^3, whose traffic is worth 0.08 ms.  Differences to k_wgrad16z:
+//   * column = 4 x 32 OUTPUT voxels; an output plane o needs the input planes 2 o - 1, 2 o, 2 o + 1 (9 rows x 65 columns each):
+//     a ring of exactly three LDS images -- plane 2 o + 1 stays for o + 1, the other two are replaced IN PLACE behind the
+//     plane's first barrier by the two planes that travelled in registers while plane o was multiplied;
+//   * the x image is split by the parity of the input column, [input row 9][parity 2][34 slots][64 B] (as k_fwd16ys): tap
+//     dx reads parity dx & 1 at unit stride; dx = 0 and dx = 2 of a (dz, dy) pair share three reads of the even line (the
+//     odd shift is four v_alignbit), dx = 1 takes two of the odd line: 5 reads + 4 shifts per triple;
+//   * a workgroup multiplies one 32-channel block of x with TWO 32-channel blocks of dy (14 accumulators per wave): x is
+//     read once for K = 64; no ones slot -- the bias gradient of these layers takes the column-sum pass.
+constexpr int WS_TH = 4, WS_TW = 32, WS_ROWS = 2 * WS_TH + 1, WS_COLS = 2 * WS_TW + 1;
+constexpr int WS_LP = WS_TW + 2;                          // slots per (input row, parity) line: 33 used
+constexpr int WS_LPB = WS_LP * 64;                        // 2176 B
+constexpr int WS_PLANE = WS_ROWS * 2 * WS_LPB;            // 39168 B per x plane image
+constexpr int WS_DYB = WS_TH * WS_TW * 64;                // 8192 B per (dy plane, 32-channel block)
+constexpr int WS_BOFF = 3 * WS_PLANE;                     // 117504
+constexpr int WS_LDS = WS_BOFF + 2 * WS_DYB;              // one dy plane, two channel blocks
+constexpr int WS_APARTS = WS_ROWS * WS_COLS * 4;          // 2340 16-byte parts per x plane
+constexpr int WS_NA = (WS_APARTS + 255) / 256;            // 10
+constexpr int WS_NB = 2 * WS_TH * WS_TW * 4 / 256;        // 4
+static_assert(WS_LDS <= 160 * 1024, "k_wgrad16zs: LDS budget");
+static_assert((WS_ROWS * 2) * WS_LPB + 16 * 64 + 512 < 65536, "ds_read immediates");
+
+__global__ __launch_bounds__(256, 1) void k_wgrad16zs(const WgradGeom g, const WgZTile tg, const unsigned short *__restrict__ a1,
+                                                      const unsigned short *__restrict__ b, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.y / tg.nkb, kb2 = blockIdx.y % tg.nkb;   // 32 reduce channels x 64 produce channels
+    const int split = blockIdx.x;
+    const int C = g.C1, K = g.K;
+    const int c0 = cb * 32, k0 = kb2 * 64;
+    const int Do = g.Do, Ho = g.Ho, Wo = g.Wo, Di = g.Di, Hi = g.Hi, Wi = g.Wi;
+
+    f32x16w acc[2][7];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[q][j][r] = 0.f;
+
+    const int q4 = (lane & 15) >> 2;
+    const int colb = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds8 + (unsigned)((8 * h + q4) * 64 + colb);
+    // triples 2 w, 2 w + 1 over (dz, dy) = (T / 3, T % 3); single tap dx = w of the ninth pair (dz = dy = 2), waves 0 .. 2
+    const int T0 = 2 * wave, T1 = 2 * wave + 1;
+    const int dzq0 = T0 / 3, dzq1 = T1 / 3;
+    const unsigned bq0 = lane_base + (unsigned)((T0 % 3) * 2 * WS_LPB);   // input row 2 r + dy: dy rows of two lines each
+    const unsigned bq1 = lane_base + (unsigned)((T1 % 3) * 2 * WS_LPB);
+    const bool has_single = wave < 3;
+    const unsigned bs_ = lane_base + (unsigned)(2 * 2 * WS_LPB + (wave & 1) * WS_LPB + (wave >> 1) * 64);
+    const unsigned bB = lane_base + (unsigned)WS_BOFF;
+
+    // staging roles: x plane part idx = u * 256 + tid -> (input row, input column, part); LDS address by column parity
+    int rrA[WS_NA], ccA[WS_NA];
+    unsigned ldsA[WS_NA];
+#pragma unroll
+    for (int u = 0; u < WS_NA; u++) {
+        const int idx = u * 256 + tid;
+        const int slot = idx >> 2, part = idx & 3;
+        const int R = slot / WS_COLS, X = slot - R * WS_COLS;
+        rrA[u] = idx < WS_APARTS ? R : -100;
+        ccA[u] = X;
+        ldsA[u] = (unsigned)((R * 2 + (X & 1)) * WS_LPB + (X >> 1) * 64 + part * 16);
+    }
+
+    for (int unit = split; unit < tg.nunits; unit += tg.nsplit) {
+        unsigned r_ = (unsigned)unit;
+        const int zc_ = (int)(r_ % (unsigned)tg.nzc); r_ /= (unsigned)tg.nzc;
+        const int tx_ = (int)(r_ % (unsigned)tg.ntx); r_ /= (unsigned)tg.ntx;
+        const int ty_ = (int)(r_ % (unsigned)tg.nty);
+        const int n = (int)(r_ / (unsigned)tg.nty);
+        const int y0 = ty_ * WS_TH, x0 = tx_ * WS_TW;     // output coordinates
+        const int z0 = zc_ * tg.zc;
+        const int nz = min(tg.zc, Do - z0);
+        unsigned voA[WS_NA], voB[WS_NB];
+#pragma unroll
+        for (int u = 0; u < WS_NA; u++) {
+            const int gy = 2 * y0 - 1 + rrA[u], gx = 2 * x0 - 1 + ccA[u];
+            const bool ok = rrA[u] >= 0 && gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+            voA[u] = ok ? (unsigned)(((rrA[u] * Wi + ccA[u]) * C) * 2 + ((u * 256 + tid) & 3) * 16) : 0x80000000u;
+        }
+#pragma unroll
+        for (int u = 0; u < WS_NB; u++) {   // dy plane: idx -> (channel block q, voxel, part)
+            const int idx = u * 256 + tid;
+            const int qb = idx >> 9, v = (idx >> 2) & 127, r = v >> 5, c = v & 31;
+            const bool ok = y0 + r < Ho && x0 + c < Wo;
+            voB[u] = ok ? (unsigned)(((r * Wo + c) * K + qb * 32) * 2 + (idx & 3) * 16) : 0x80000000u;
+        }
+        const long planeA = (long)Hi * Wi * C * 2, planeB = (long)Ho * Wo * K * 2;
+        const char *cornerA = reinterpret_cast<const char *>(a1) + ((long)n * Di * planeA + ((long)(2 * y0 - 1) * Wi + (2 * x0 - 1)) * C * 2 + c0 * 2);
+        const char *cornerB = reinterpret_cast<const char *>(b) + ((long)n * Do * planeB + ((long)y0 * Wo + x0) * K * 2 + k0 * 2);
+        auto rsrcA = [&](int z, bool want) {  // input plane z
+            const bool ok = want && z >= 0 && z < Di;
+            return wz_rsrc(cornerA + (ok ? (long)z * planeA : 0), ok);
+        };
+        auto rsrcB = [&](int z, bool want) {  // output (dy) plane z
+            const bool ok = want && z >= 0 && z < Do;
+            return wz_rsrc(cornerB + (ok ? (long)z * planeB : 0), ok);
+        };
+        u32x4z ra[2][WS_NA], rb[WS_NB];
+        auto write_A = [&](int slot, const u32x4z (&r)[WS_NA]) {
+#pragma unroll
+            for (int u = 0; u < WS_NA; u++)
+                if (u < WS_NA - 1 || tid < WS_APARTS - (WS_NA - 1) * 256)
+                    *reinterpret_cast<u32x4z *>(lds8 + slot * WS_PLANE + ldsA[u]) = r[u];
+        };
+        auto write_B = [&]() {
+#pragma unroll
+            for (int u = 0; u < WS_NB; u++) *reinterpret_cast<u32x4z *>(lds8 + WS_BOFF + (u * 256 + tid) * 16) = rb[u];
+        };
+        auto load_A = [&](u32x4z (&r)[WS_NA], const u32x4z d) {
+#pragma unroll
+            for (int u = 0; u < WS_NA; u++) wz_bload(r[u], voA[u], d);
+        };
+        auto load_B = [&](const u32x4z d) {
+#pragma unroll
+            for (int u = 0; u < WS_NB; u++) wz_bload(rb[u], voB[u], d);
+        };
+        auto slot_of = [&](int zin) { return ((zin % 3) + 3) % 3; };   // ring slot of input plane zin (any sign)
+        // ---- prologue: input plane 2 z0 - 1 into its slot; planes 2 z0, 2 z0 + 1 and dy plane z0 into the registers
+        __syncthreads();
+        load_A(ra[0], rsrcA(2 * z0 - 1, true));
+        wz_wait<0>(ra[0]);
+        write_A(slot_of(2 * z0 - 1), ra[0]);
+        load_A(ra[0], rsrcA(2 * z0, true));
+        load_A(ra[1], rsrcA(2 * z0 + 1, true));
+        load_B(rsrcB(z0, true));
+
+        s16x4w rt[2][2][5], rs[2][2], rv[2][2][2];   // [buf][triple][read], single [buf][read], dy [buf][block][read]
+        for (int p = 0; p < nz; p++) {
+            const int o = z0 + p;
+            asm volatile("s_barrier" ::: "memory");   // every wave has finished the previous plane's reads
+            wz_wait<WS_NA + WS_NB>(ra[0]);
+            write_A(slot_of(2 * o), ra[0]);
+            wz_wait<WS_NB>(ra[1]);
+            write_A(slot_of(2 * o + 1), ra[1]);
+            wz_wait<0>(rb);
+            write_B();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // the next output plane's inputs travel while this one is multiplied
+            load_A(ra[0], rsrcA(2 * o + 2, p + 1 < nz));
+            load_A(ra[1], rsrcA(2 * o + 3, p + 1 < nz));
+            load_B(rsrcB(o + 1, p + 1 < nz));
+            const unsigned aq0 = bq0 + (unsigned)(slot_of(2 * o - 1 + dzq0) * WS_PLANE);
+            const unsigned aq1 = bq1 + (unsigned)(slot_of(2 * o - 1 + dzq1) * WS_PLANE);
+            const unsigned as = bs_ + (unsigned)(slot_of(2 * o + 1) * WS_PLANE);
+            auto fetch = [&](int st, int buf) {
+                const int r = st >> 1, sx = st & 1;
+                const int imm = (2 * r) * 2 * WS_LPB + sx * 16 * 64;         // input row 2 r (+ dy in the base), even line
+                const int immB = (r * WS_TW + sx * 16) * 64;
+                rv[buf][0][0] = wz_trd(bB + immB);
+                rv[buf][0][1] = wz_trd(bB + immB + 256);
+                rv[buf][1][0] = wz_trd(bB + immB + WS_DYB);
+                rv[buf][1][1] = wz_trd(bB + immB + WS_DYB + 256);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const unsigned a = q ? aq1 : aq0;
+                    rt[buf][q][0] = wz_trd(a + imm);                  // even line: columns c .. c + 3   (dx = 0: elements 0 .. 7)
+                    rt[buf][q][1] = wz_trd(a + imm + 256);            //            c + 4 .. c + 7
+                    rt[buf][q][2] = wz_trd(a + imm + 512);            //            c + 8 .. c + 11     (dx = 2: elements 1 .. 8)
+                    rt[buf][q][3] = wz_trd(a + imm + WS_LPB);         // odd line (dx = 1)
+                    rt[buf][q][4] = wz_trd(a + imm + WS_LPB + 256);
+                }
+                if (has_single) {   // wave-uniform
+                    rs[buf][0] = wz_trd(as + imm);
+                    rs[buf][1] = wz_trd(as + imm + 256);
+                }
+            };
+            auto mfmas = [&](int buf) {
+                bf16x8z bf[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+                    bf[q] = __builtin_bit_cast(bf16x8z, __builtin_shufflevector(rv[buf][q][0], rv[buf][q][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                s16x8w f0[2], f1[2], f2[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    f0[q] = __builtin_shufflevector(rt[buf][q][0], rt[buf][q][1], 0, 1, 2, 3, 4, 5, 6, 7);   // dx = 0
+                    f1[q] = __builtin_shufflevector(rt[buf][q][3], rt[buf][q][4], 0, 1, 2, 3, 4, 5, 6, 7);   // dx = 1
+                    const s16x8w t12 = __builtin_shufflevector(rt[buf][q][1], rt[buf][q][2], 0, 1, 2, 3, 4, 5, 6, 7);
+                    f2[q] = __builtin_shufflevector(f0[q], t12, 1, 2, 3, 4, 5, 6, 7, 12);                     // dx = 2
+                }
+#pragma unroll
+                for (int kq = 0; kq < 2; kq++) {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        acc[kq][3 * q + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f0[q]), bf[kq], acc[kq][3 * q + 0], 0, 0, 0);
+                        acc[kq][3 * q + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f1[q]), bf[kq], acc[kq][3 * q + 1], 0, 0, 0);
+                    }
+                }
+                if (has_single) {
+                    const bf16x8z sfrag = __builtin_bit_cast(bf16x8z, __builtin_shufflevector(rs[buf][0], rs[buf][1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int kq = 0; kq < 2; kq++)
+                        acc[kq][6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sfrag, bf[kq], acc[kq][6], 0, 0, 0);
+                }
+#pragma unroll
+                for (int kq = 0; kq < 2; kq++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++)
+                        acc[kq][3 * q + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8z, f2[q]), bf[kq], acc[kq][3 * q + 2], 0, 0, 0);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int st = 0; st < 2 * WS_TH; st++) {
+                if (st + 1 < 2 * WS_TH) fetch(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(st & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last plane's zero-record loads)
+    }
+#pragma unroll
+    for (int kq = 0; kq < 2; kq++)
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int t = j < 6 ? 6 * wave + j : 24 + wave;
+            if (t < 27) {
+                float *po = partial + ((size_t)split * 27 + t) * C * K;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    po[(size_t)(c0 + row) * K + k0 + 32 * kq + i] = acc[kq][j][r];
+                }
+            }
+        }
+}
+
 static int &wgrad16z_mode() {
     static int v = getenv("MVD_WGRAD16Z") ? atoi(getenv("MVD_WGRAD16Z")) : 1;
     return v;
@@ -537,6 +774,69 @@ int wgrad16z(const WgradGeom &g, const unsigned short *a1, const unsigned short 
     if (check_launch("conv wgrad (bf16 z-marching)")) return 1;
     *nsplit_out = tg.nsplit;
     *pbias_out = pbias;
+    return 0;
+}
+
+
+// stride-2 twin: -1 when the problem is not this kernel's, 0 after a launch (partials [nsplit][27][C][K] in ws; no bias rows)
+int wgrad16zs(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,
+              size_t ws_bytes, int *nsplit_out, hipStream_t s) {
+    static const int on = getenv("MVD_WGRAD16ZS") ? atoi(getenv("MVD_WGRAD16ZS")) : 1;
+    if (!on || !wgrad16z_mode()) return -1;
+    if (g.ntaps != 27 || g.T != 27 || g.C1 % 32 != 0 || g.C2 != 0 || a2 != nullptr || g.K % 64 != 0) return -1;
+    for (int a = 0; a < 3; a++)
+        if (g.sa[a] != 2 || g.sb[a] != 1) return -1;
+    for (int t = 0; t < 27; t++)
+        if (g.off[t][0] != t / 9 - 1 || g.off[t][1] != (t / 3) % 3 - 1 || g.off[t][2] != t % 3 - 1 || g.ob[t][0] != 0 ||
+            g.ob[t][1] != 0 || g.ob[t][2] != 0)
+            return -1;
+    if (g.Db != g.Do || g.Hb != g.Ho || g.Wb != g.Wo) return -1;
+    if (g.Do != (g.Di - 1) / 2 + 1 || g.Ho != (g.Hi - 1) / 2 + 1 || g.Wo != (g.Wi - 1) / 2 + 1) return -1;
+    if (g.Wo < 32 || g.Ho < 4 || g.Do < 4) return -1;
+    if ((long)g.Hi * g.Wi * g.C1 * 2 >= (1L << 31) || (long)g.Ho * g.Wo * g.K * 2 >= (1L << 31)) return -1;
+    WgZTile tg;
+    tg.nty = (g.Ho + WS_TH - 1) / WS_TH;
+    tg.ntx = (g.Wo + WS_TW - 1) / WS_TW;
+    const int ncb = g.C1 / 32;
+    tg.nkb = g.K / 64;
+    const long blocks = (long)ncb * tg.nkb;
+    if (blocks > 65535) return -1;
+    const long columns = (long)g.N * tg.nty * tg.ntx;
+    const long per_round = blocks >= 256 ? 1 : 256 / blocks;
+    long best_cost = -1;
+    int best_nzc = 1;
+    for (int nzc = 1; nzc <= 32 && nzc * 4 <= g.Do; nzc++) {
+        const int zc = (g.Do + nzc - 1) / nzc;
+        const int nzc_eff = (g.Do + zc - 1) / zc;
+        const long units = columns * nzc_eff;
+        const long rounds = (units + per_round - 1) / per_round;
+        const long cost = rounds * (2 * zc + 3);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_nzc = nzc_eff;
+        }
+    }
+    tg.zc = (g.Do + best_nzc - 1) / best_nzc;
+    tg.nzc = (g.Do + tg.zc - 1) / tg.zc;
+    const long units = columns * tg.nzc;
+    if (units > (1L << 30) || units * blocks < 128) return -1;   // (small problems: the tiled kernel)
+    tg.nunits = (int)units;
+    const long rounds = (units + per_round - 1) / per_round;
+    tg.nsplit = (int)((units + rounds - 1) / rounds);
+    const size_t need = (size_t)tg.nsplit * 27 * g.C1 * g.K * sizeof(float);
+    if (need > ws_bytes) return -1;
+    static PerDeviceFlag cfgd;
+    if (!cfgd()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad16zs), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS) !=
+            hipSuccess) {
+            set_error("conv wgrad (bf16 z-marching, stride 2): cannot raise the dynamic LDS limit");
+            return 1;
+        }
+        cfgd() = true;
+    }
+    hipLaunchKernelGGL(k_wgrad16zs, dim3(tg.nsplit, (unsigned)blocks), dim3(256), WS_LDS, s, g, tg, a1, b, reinterpret_cast<float *>(ws));
+    if (check_launch("conv wgrad (bf16 z-marching, stride 2)")) return 1;
+    *nsplit_out = tg.nsplit;
     return 0;
 }
 

@@ -99,6 +99,9 @@ int wgrad16z_run(const WgradGeom &g, const unsigned short *a1, const unsigned sh
                  size_t ws_bytes, hipStream_t s, float *dbias, int *dbias_done, const float *in_scale, const float *in_shift,
                  float slope);
 bool wgrad16z_prologue_ok(const WgradGeom &g);
+// stride-2 twin (k_wgrad16zs): partials only, the bias gradient stays with the caller's column-sum pass
+int wgrad16zs(const WgradGeom &g, const unsigned short *a1, const unsigned short *a2, const unsigned short *b, void *ws,
+              size_t ws_bytes, int *nsplit_out, hipStream_t s);
 void wgrad16z_enable(int on);
 int pack_weights_batch(int n, const float *const *w, float *const *wf, float *const *wb, float *const *uf, float *const *ub,
                        const int *K, const int *C, const int *T, const int *transposed, hipStream_t s);

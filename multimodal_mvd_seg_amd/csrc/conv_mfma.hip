@@ -2811,6 +2811,15 @@ int wgrad_mfma(const WgradGeom &g, const float *a1, const float *a2, const float
                                     reinterpret_cast<const unsigned short *>(b), dw, ws, ws_bytes, s, dbias, dbias_done, nullptr,
                                     nullptr, 0.f);
         if (rz >= 0) return rz;
+        int nsplit_s = 0;   // stride 2: k_wgrad16zs (no bias rows: dbias_done stays 0, the caller runs the column sums)
+        const int rs2 = wgrad16zs(g, reinterpret_cast<const unsigned short *>(a1), reinterpret_cast<const unsigned short *>(a2),
+                                  reinterpret_cast<const unsigned short *>(b), ws, ws_bytes, &nsplit_s, s);
+        if (rs2 > 0) return rs2;
+        if (rs2 == 0) {
+            launch_wgrad_reduce_f((unsigned)cdiv((long)27 * C * g.K, 64), s, g, reinterpret_cast<float *>(ws), dw, nsplit_s,
+                                  (const float *)nullptr, (float *)nullptr, 0, 0);
+            return check_launch("conv wgrad reduce (bf16 z-marching, stride 2)");
+        }
     }
     WgTile tg;
     memset(&tg, 0, sizeof(tg));

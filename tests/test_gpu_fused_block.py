@@ -562,3 +562,34 @@ def test_fwd16ys_stride2_forward_exact_integer_data(N, D, H, W):
         assert torch.equal(y.cpu(), ref), f"kernel {which}: {int((y.cpu() != ref).sum())} of {ref.numel()} differ"
         outs.append(y)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("C,K,N,D,H,W", [(32, 64, 2, 128, 128, 128), (32, 64, 1, 131, 127, 129), (64, 128, 2, 64, 64, 64),
+                                          (32, 64, 1, 16, 24, 70)])
+def test_wgrad16zs_stride2_weight_gradient_exact_integer_data(C, K, N, D, H, W):
+    """k_wgrad16zs (z-marching weight gradient of the 3x3x3 stride-2 convs: ring of three parity-split x planes replaced in
+    place, two dy channel blocks per workgroup) on small-integer data: dw (and db, from the column-sum pass) must equal
+    torch's exact fp32 result bit for bit -- even and odd input extents, one and two reduce-channel blocks, chunked z ranges;
+    the tiled kernel on the same data must agree."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(D + 3 * W + C)
+    ints = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=g).float()
+    x, w, b = ints((N, C, D, H, W), -2, 2), ints((K, C, 3, 3, 3), -1, 1), ints((K,), -1, 1)
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    y_ref = F.conv3d(x, wr, br, 2, 1)
+    gy = ints(tuple(y_ref.shape), -1, 1)
+    y_ref.backward(gy)
+    res = []
+    for which in (1, 0):
+        _set_wgrad_kernel(which)
+        try:
+            gx = x.to(DEV).to(BF).contiguous(memory_format=CL)
+            gw, gb = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+            y = ops.Conv3dFn.apply(gx, None, gw, gb, (2, 2, 2))
+            y.backward(gy.to(DEV).to(BF).contiguous(memory_format=CL))
+        finally:
+            _set_wgrad_kernel(1)
+        assert torch.equal(gw.grad.cpu(), wr.grad), f"dw (kernel {which}): {int((gw.grad.cpu() != wr.grad).sum())} of {wr.grad.numel()} differ"
+        assert torch.equal(gb.grad.cpu(), br.grad), f"db (kernel {which})"
+        res.append(gw.grad)
+    assert torch.equal(res[0], res[1])
