@@ -593,3 +593,52 @@ def test_wgrad16zs_stride2_weight_gradient_exact_integer_data(C, K, N, D, H, W):
         assert torch.equal(gb.grad.cpu(), br.grad), f"db (kernel {which})"
         res.append(gw.grad)
     assert torch.equal(res[0], res[1])
+
+
+def test_round3_kernels_are_run_to_run_deterministic():
+    """The z-marching kernels carry hand-placed schedules (inline-asm MFMAs, counted waits, pinned accumulator resets): a missing
+    wait state shows as SPORADICALLY different results, not as a wrong test case (that is how the stale-accumulator bug of
+    k_fwd16y was found).  Twelve repetitions of each kernel on the same inputs must be bit-identical."""
+    from multimodal_mvd_seg_amd import ops
+    from multimodal_mvd_seg_amd._lib import call, i3, query
+    g = torch.Generator().manual_seed(77)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    reps = 12
+
+    def same(fn, what):
+        first = fn()
+        for k in range(reps - 1):
+            out = fn()
+            for a, b in zip(first, out):
+                assert torch.equal(a, b), f"{what}: repetition {k + 1} differs ({int((a != b).sum())} values)"
+
+    N, D, H, W = 2, 64, 64, 64
+    for C, K, stride in ((32, 32, 1), (64, 64, 1), (32, 64, 2)):   # k_fwd16y (one / two chunks), k_fwd16ys; their weight gradients
+        S = 2 * D if stride == 2 else D
+        x = rnd(N, C, S, S, S).to(BF).to(DEV).contiguous(memory_format=CL)
+        w = (rnd(K, C, 3, 3, 3) / np.sqrt(27 * C)).to(DEV)
+        b = (rnd(K) * 0.1).to(DEV)
+        gy = rnd(N, K, D, D, D).to(BF).to(DEV).contiguous(memory_format=CL)
+
+        def step():
+            xx = x.clone().requires_grad_(stride == 1)
+            ww, bb = w.clone().requires_grad_(), b.clone().requires_grad_()
+            y = ops.Conv3dFn.apply(xx, None, ww, bb, (stride,) * 3)
+            y.backward(gy)
+            return [y.detach(), ww.grad, bb.grad] + ([xx.grad] if stride == 1 else [])
+        same(step, f"conv {C}->{K} stride {stride}")
+    # the fused node (forward loader prologue + statistics epilogue, weight-gradient loader prologue), 32 and 64 channels
+    for C in (32, 64):
+        y0 = (rnd(N, C, D, D, D) * 1.5 + 0.3).to(BF).to(DEV).contiguous(memory_format=CL)
+        w = (rnd(C, C, 3, 3, 3) / np.sqrt(27 * C)).to(DEV)
+        b = (rnd(C) * 0.1).to(DEV)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (rnd(C) * 0.2).to(DEV)
+        gy = rnd(N, C, D, D, D).to(BF).to(DEV).contiguous(memory_format=CL)
+
+        def fused():
+            yy = y0.clone().requires_grad_()
+            ps = [t.clone().requires_grad_() for t in (gamma, beta, w, b)]
+            y1 = ops.NormActConv3dFn.apply(yy, ps[0], ps[1], 1e-5, 0.01, ps[2], ps[3])
+            y1.backward(gy)
+            return [y1.detach(), yy.grad] + [p.grad for p in ps]
+        same(fused, f"fused block {C} channels")
