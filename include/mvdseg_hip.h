@@ -217,6 +217,16 @@ int mvd_seghead_fwd_bf16(const uint16_t *x, const float *w, const float *bias, f
                          int K, void *stream);
 int mvd_seghead_bwd_bf16(const uint16_t *x, const float *w, const float *dlogits, uint16_t *dx, float *dw, float *dbias,
                          int N, long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream);
+/* The seg head of the LAST decoder stage reading the RAW bf16 output of that stage's last conv (UNetDecoder.py:110 after
+ * get_network_from_plans.py:41-44): a = bf16(lrelu(x * scale[n][c] + shift[n][c])) is applied in the loaders, the activated
+ * tensor is not materialised.  _bwd: dx = d a (the caller runs the InstanceNorm backward on it), dw / dbias over the
+ * re-computed a.  Bit-identical to mvd_seghead_*_bf16 over the tensor mvd_instnorm_lrelu_apply_bf16 would write. */
+int mvd_seghead_bf16_fused_ok(int N, long V, int C, int K);
+int mvd_seghead_fwd_bf16_fused(const uint16_t *x, const float *scale, const float *shift, float slope, const float *w,
+                               const float *bias, float *logits, int N, long V, int C, int K, void *stream);
+int mvd_seghead_bwd_bf16_fused(const uint16_t *x, const float *scale, const float *shift, float slope, const float *w,
+                               const float *dlogits, uint16_t *dx, float *dw, float *dbias, int N, long V, int C, int K,
+                               int accumulate, void *ws, size_t ws_bytes, void *stream);
 /* flat conversions (round-to-nearest-even) for tensors that cross the precision boundary (distillation features) */
 int mvd_cast_f32_to_bf16(const float *src, uint16_t *dst, long n, void *stream);
 int mvd_cast_bf16_to_f32(const uint16_t *src, float *dst, long n, void *stream);

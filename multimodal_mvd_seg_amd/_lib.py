@@ -72,6 +72,10 @@ SIGNATURES = {
                                             c_size_t, _P]),
     "mvd_seghead_fwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_long, c_int, c_int, _P]),
     "mvd_seghead_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "mvd_seghead_bf16_fused_ok": (c_int, [c_int, c_long, c_int, c_int]),
+    "mvd_seghead_fwd_bf16_fused": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_long, c_int, c_int, _P]),
+    "mvd_seghead_bwd_bf16_fused": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_int, c_int, _P,
+                                           c_size_t, _P]),
     "mvd_cast_f32_to_bf16": (c_int, [_P, _P, c_long, _P]),
     "mvd_cast_bf16_to_f32": (c_int, [_P, _P, c_long, _P]),
     "mvd_pack_weight_bf16": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

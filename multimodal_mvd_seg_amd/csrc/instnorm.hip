@@ -101,8 +101,12 @@ __global__ void k_in_stats(const float *__restrict__ x, double *__restrict__ par
     }
 }
 
+// scale / shift (optional): the fused form scale = gamma * rstd, shift = beta - mean * scale of the bf16 path (the expression
+// of k_in_scale_shift / k_in_finalize_tiles on the float-rounded mean and rstd)
 __global__ void k_in_finalize(const double *__restrict__ partial, float *__restrict__ mean, float *__restrict__ rstd,
-                              int C, int nblk, long V, float eps) {
+                              int C, int nblk, long V, float eps, const float *__restrict__ gamma = nullptr,
+                              const float *__restrict__ beta = nullptr, float *__restrict__ scale = nullptr,
+                              float *__restrict__ shift = nullptr) {
     // one wave per (n, c): lanes stride over the block partials, fixed shuffle tree (deterministic)
     const int n = blockIdx.y, c = blockIdx.x;
     double a = 0, q = 0, a1 = 0, q1 = 0;
@@ -123,8 +127,14 @@ __global__ void k_in_finalize(const double *__restrict__ partial, float *__restr
     double m = a / (double)V;
     double var = q / (double)V - m * m;
     if (var < 0) var = 0;
-    mean[(size_t)n * C + c] = (float)m;
-    rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+    mean[(size_t)n * C + c] = mf;
+    rstd[(size_t)n * C + c] = rf;
+    if (scale) {
+        const float sc = gamma[c] * rf;
+        scale[(size_t)n * C + c] = sc;
+        shift[(size_t)n * C + c] = fmaf(-mf, sc, beta[c]);
+    }
 }
 
 // conv-epilogue statistics: per-tile partials [n][tile][C][2] (fp32 sums of <= 128 values each) -> per-block fp64
@@ -619,8 +629,25 @@ static int in_fwd(const float *x, bool xb, const float *gamma, const float *beta
         else
             hipLaunchKernelGGL((k_in_stats<1, false>), grid, dim3(g.threads), sm, s, x, partial, C, g.CG, g.R, V, g.chunk);
         if (check_launch("instnorm stats")) return 1;
-        hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
+        // bf16 in and out: the apply pass takes the scale / shift form -- ONE arithmetic for the stand-alone pass, the apply after
+        // a conv's statistics epilogue and the loader prologues (conv, weight gradient, seg head), so fused and un-fused
+        // networks agree bit for bit whichever kernel produced the statistics
+        float *ss = reinterpret_cast<float *>(partial + (size_t)N * g.nblk * C * 2);
+        const bool ssf = v4 && xb && yb;
+        hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps,
+                           ssf ? gamma : nullptr, ssf ? beta : nullptr, ssf ? ss : nullptr, ssf ? ss + (size_t)N * C : nullptr);
         if (check_launch("instnorm finalize")) return 1;
+        if (ssf) {
+            long nb2 = V / ((long)g.R * 8);
+            if (nb2 < 1) nb2 = 1;
+            long cap2 = 8192 / N > 0 ? 8192 / N : 1;
+            if (nb2 > cap2) nb2 = cap2;
+            const long chunk2 = cdiv(V, nb2);
+            hipLaunchKernelGGL(k_in_apply_ss16, dim3((unsigned)cdiv(V, chunk2), N), dim3(g.threads), 0, s,
+                               reinterpret_cast<const unsigned short *>(x), ss, ss + (size_t)N * C,
+                               reinterpret_cast<unsigned short *>(y), C, g.CG, g.R, V, chunk2, slope);
+            return check_launch("instnorm apply (scale / shift form)");
+        }
     }
     long per_n = V * C / (v4 ? 4 : 1);
     long bx = cdiv(per_n, 256);
@@ -748,10 +775,8 @@ int mvd_instnorm_stats_bf16(const void *x, int x_is_bf16, const float *gamma, co
     else
         hipLaunchKernelGGL((k_in_stats<4, false>), dim3(g.nblk, N), dim3(g.threads), sm, s, xf, partial, C, g.CG, g.R, V, g.chunk);
     if (check_launch("instnorm stats")) return 1;
-    hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps);
-    if (check_launch("instnorm finalize")) return 1;
-    hipLaunchKernelGGL(k_in_scale_shift, dim3((N * C + 255) / 256), dim3(256), 0, s, gamma, beta, mean, rstd, scale, shift, N, C);
-    return check_launch("instnorm scale/shift");
+    hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps, gamma, beta, scale, shift);
+    return check_launch("instnorm finalize");
 }
 
 int mvd_instnorm_lrelu_apply_bf16(const uint16_t *x, const float *scale, const float *shift, uint16_t *y, int N, long V,

@@ -79,10 +79,24 @@ __global__ void k_seghead_dx(const float *__restrict__ dl, const float *__restri
 // C % 4 == 0 fast paths (HBM-bound: the tiled kernels above ran at 2-3 TB/s on the 128^3 head).
 // fwd: one thread per voxel, the C channels as C/4 16-byte loads all in flight, weights as scalar operands; the
 // accumulation order per class is the channel order of k_seghead_fwd (same result).  Planar logits: coalesced stores.
-template <bool XB>
+// PRO (round 3, ops.NormActSegHeadFn): x is the RAW bf16 output of the last decoder conv; the head reads
+// a = bf16(lrelu(fma(x, scale[n][c], shift[n][c]))) -- the arithmetic of k_in_apply_ss16, rounded to bf16 like the tensor that
+// pass would have written -- so the activated tensor of the last block is never materialised.
+__device__ inline float4 seg_pro4(float4 q, const float *__restrict__ sc, const float *__restrict__ sh, float slope) {
+    float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float z = fmaf(f[i], sc[i], sh[i]);
+        const float a = fmaxf(z, z * slope);
+        f[i] = __uint_as_float((unsigned)f2bf(a) << 16);
+    }
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+template <bool XB, bool PRO = false>
 __global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict__ x, const float *__restrict__ w,
                                                          const float *__restrict__ bias, float *__restrict__ logits, long V,
-                                                         int C, int K) {
+                                                         int C, int K, const float *__restrict__ scale = nullptr,
+                                                         const float *__restrict__ shift = nullptr, float slope = 0.f) {
     const int n = blockIdx.y;
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
@@ -97,6 +111,11 @@ __global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict
         if (full) {
 #pragma unroll
             for (int j = 0; j < 8; j++) q[j] = ld4<XB>(x, xo + c0 + 4 * j);
+            if (PRO) {   // (host: C % 32 == 0) scale / shift of sample n: wave-uniform, scalar loads
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    q[j] = seg_pro4(q[j], scale + (size_t)n * C + c0 + 4 * j, shift + (size_t)n * C + c0 + 4 * j, slope);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; j++) q[j] = (c0 + 4 * j < C) ? ld4<XB>(x, xo + c0 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -326,9 +345,10 @@ __global__ void k_seghead_dw4(const float *__restrict__ x, const float *__restri
 
 // V % 4 == 0 variant: a thread walks QUADS of consecutive voxels, so the planar dlogits come in as one float4 per
 // class (instead of 4 scalar loads) next to the 4 channel rows; no per-voxel division (n, v advance incrementally)
-template <bool XB>
+template <bool XB, bool PRO = false>
 __global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
-                               int N, long V, int C, int K, long chunk) {
+                               int N, long V, int C, int K, long chunk, const float *__restrict__ scale = nullptr,
+                               const float *__restrict__ shift = nullptr, float slope = 0.f) {
     extern __shared__ float smf[];  // [R][K*C + K]
     const int t = threadIdx.x;
     const int CG = C / 4, R = blockDim.x / CG;
@@ -353,6 +373,12 @@ __global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restr
             float4 q[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) q[u] = ld4<XB>(x, (size_t)(i + u) * C + g * 4);
+            if (PRO) {   // the four voxels i .. i + 3 belong to one sample (V % 4 == 0): its scale / shift of this lane's channels
+                const float *sc = scale + (size_t)n * C + g * 4, *sh = shift + (size_t)n * C + g * 4;
+                const float s4[4] = {sc[0], sc[1], sc[2], sc[3]}, h4[4] = {sh[0], sh[1], sh[2], sh[3]};
+#pragma unroll
+                for (int u = 0; u < 4; u++) q[u] = seg_pro4(q[u], s4, h4, slope);
+            }
             float4 dq[KMAX];  // (all classes in flight at once, see k_seghead_dx4)
 #pragma unroll
             for (int k = 0; k < KMAX; k++)
@@ -848,7 +874,8 @@ static int seghead_fwd_impl(const float *x, bool xb, const float *w, const float
     }
     if (C % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
         auto kv = xb ? k_seghead_fwd_vox<true> : k_seghead_fwd_vox<false>;
-        hipLaunchKernelGGL(kv, dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C, K);
+        hipLaunchKernelGGL(kv, dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C, K,
+                           (const float *)nullptr, (const float *)nullptr, 0.f);
         return check_launch("seghead_fwd");
     }
     auto kern = xb ? k_seghead_fwd<true> : k_seghead_fwd<false>;
@@ -915,7 +942,7 @@ static int seghead_bwd_impl(const float *x, bool xb, const float *w, const float
         const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
         if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0 && V % 4 == 0 && (((uintptr_t)dlogits) & 15) == 0)
             hipLaunchKernelGGL(xb ? k_seghead_dw4v<true> : k_seghead_dw4v<false>, dim3(nblk), dim3((R * CG + 63) / 64 * 64),
-                               smb, s, x, dlogits, partial, N, V, C, K, chunk);
+                               smb, s, x, dlogits, partial, N, V, C, K, chunk, (const float *)nullptr, (const float *)nullptr, 0.f);
         else if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0)
             hipLaunchKernelGGL(xb ? k_seghead_dw4<true> : k_seghead_dw4<false>, dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s, x, dlogits, partial, N, V,
                                C, K, chunk);
@@ -938,6 +965,56 @@ int mvd_seghead_bwd_bf16(const uint16_t *x, const float *w, const float *dlogits
                          int N, long V, int C, int K, int accumulate, void *ws, size_t ws_bytes, void *stream) {
     return seghead_bwd_impl(reinterpret_cast<const float *>(x), true, w, dlogits, reinterpret_cast<float *>(dx), dw, dbias,
                             N, V, C, K, accumulate, ws, ws_bytes, stream);
+}
+
+// ---- the seg head reading the RAW output of the last decoder conv (InstanceNorm-apply + LeakyReLU in its loaders)
+int mvd_seghead_bf16_fused_ok(int N, long V, int C, int K) {
+    return (N > 0 && N <= 65535 && V > 0 && V % 4 == 0 && C % 32 == 0 && C / 4 <= 256 && K > 0 && K <= KMAX &&
+            (size_t)(256 / (C / 4)) * (K * C + K) * sizeof(float) <= 60 * 1024) ? 1 : 0;
+}
+
+int mvd_seghead_fwd_bf16_fused(const uint16_t *x, const float *scale, const float *shift, float slope, const float *w,
+                               const float *bias, float *logits, int N, long V, int C, int K, void *stream) {
+    MVD_REQUIRE(x && scale && shift && w && bias && logits, "seghead_fwd_bf16_fused: null pointer");
+    MVD_REQUIRE(mvd_seghead_bf16_fused_ok(N, V, C, K) && (((uintptr_t)x) & 15) == 0,
+                "seghead_fwd_bf16_fused: shape not served (query mvd_seghead_bf16_fused_ok)");
+    hipLaunchKernelGGL((k_seghead_fwd_vox<true, true>), dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float *>(x), w, bias, logits, V, C, K, scale, shift, slope);
+    return check_launch("seghead_fwd (fused InstanceNorm + LeakyReLU loader)");
+}
+
+// dx = d(activated input) (the caller runs the InstanceNorm backward on it), dw / dbias over the re-computed activation
+int mvd_seghead_bwd_bf16_fused(const uint16_t *x, const float *scale, const float *shift, float slope, const float *w,
+                               const float *dlogits, uint16_t *dx, float *dw, float *dbias, int N, long V, int C, int K,
+                               int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && scale && shift && w && dlogits && ws, "seghead_bwd_bf16_fused: null pointer");
+    MVD_REQUIRE(mvd_seghead_bf16_fused_ok(N, V, C, K) && (((uintptr_t)x | (uintptr_t)dlogits | (uintptr_t)w) & 15) == 0,
+                "seghead_bwd_bf16_fused: shape not served (query mvd_seghead_bf16_fused_ok)");
+    MVD_REQUIRE(ws_bytes >= mvd_seghead_bwd_workspace_bytes(N, V, C, K), "seghead_bwd_bf16_fused: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (dx) {   // does not read x: the plain kernel
+        MVD_REQUIRE((((uintptr_t)dx) & 15) == 0, "seghead_bwd_bf16_fused: dx alignment");
+        const long R = 256 / (C / 4);
+        long nb = cdiv(V / 4, R);
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(k_seghead_dx4<true>, dim3((unsigned)nb, N), dim3(256), 0, s, dlogits, w, reinterpret_cast<float *>(dx), V,
+                           C, K, accumulate);
+        if (check_launch("seghead_dx")) return 1;
+    }
+    if (dw) {
+        MVD_REQUIRE(dbias, "seghead_bwd_bf16_fused: dbias required with dw");
+        int nblk;
+        long chunk = seghead_chunk((long)N * V, &nblk);
+        double *partial = reinterpret_cast<double *>(ws);
+        const int CG = C / 4, R = 256 / CG;
+        const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
+        hipLaunchKernelGGL((k_seghead_dw4v<true, true>), dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s,
+                           reinterpret_cast<const float *>(x), dlogits, partial, N, V, C, K, chunk, scale, shift, slope);
+        if (check_launch("seghead_dw (fused loader)")) return 1;
+        if (reduce_partials(partial, dw, nblk, K * C, s, K * C + K, 0)) return 1;
+        if (reduce_partials(partial, dbias, nblk, K, s, K * C + K, K * C)) return 1;
+    }
+    return 0;
 }
 
 size_t mvd_dcce_workspace_bytes(int N, long V, int K) {

@@ -26,6 +26,8 @@ from . import ops
 SHARE_GRADS = [os.environ.get("MVD_SHARE_GRADS", "1") != "0"]
 FUSE_PROLOGUE = [os.environ.get("MVD_FUSE_PROLOGUE", "1") != "0"]
 FUSE_PROLOGUE_TRAIN = [os.environ.get("MVD_FUSE_PROLOGUE_TRAIN", "auto")]
+# the last decoder block's InstanceNorm + LeakyReLU inside the seg head that is its only consumer (ops.NormActSegHeadFn)
+FUSE_SEGHEAD = [os.environ.get("MVD_FUSE_SEGHEAD", "1") != "0"]
 
 
 def _tup3(v):
@@ -142,8 +144,10 @@ class StackedConvBlocks(nn.Module):
         self.output_channels = output_channels[-1]
         self.initial_stride = _tup3(initial_stride)
 
-    def forward(self, x, x2=None):
-        """conv -> norm -> act per block.  bf16 mixed precision, consecutive blocks whose second conv takes the z-marching
+    def forward(self, x, x2=None, raw_tail=False):
+        """conv -> norm -> act per block.  raw_tail (the last decoder stage in front of its seg head, bf16): the LAST block's
+        norm + act are left to the consumer -- returns (raw conv output, that block); None when the chain did not end fused.
+        bf16 mixed precision, consecutive blocks whose second conv takes the z-marching
         kernel (3x3x3, stride 1, 32 -> 32 channels at the patch resolution): the first block's InstanceNorm + LeakyReLU is
         folded into the second conv's loader (no apply pass, the activated tensor is never written) --
         in inference and, where the weight-gradient kernel has the same prologue, in training (FUSE_PROLOGUE_TRAIN)."""
@@ -152,7 +156,8 @@ class StackedConvBlocks(nn.Module):
         for i, blk in enumerate(blocks):
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
             fuse_next = nxt is not None and self._can_fuse(blk, nxt, x if raw is None else raw)
-            if raw is None and not fuse_next:
+            tail = raw_tail and nxt is None and blk.precision == "bf16" and FUSE_PROLOGUE[0]
+            if raw is None and not fuse_next and not tail:
                 x = blk(x, x2) if i == 0 else blk(x)      # the plain module call (forward hooks fire)
                 continue
             y = blk.forward_from_raw(blocks[i - 1], raw) if raw is not None else \
@@ -160,9 +165,11 @@ class StackedConvBlocks(nn.Module):
             if fuse_next and ops.fused_norm_conv_ok(y, nxt.conv.weight, nxt.stride):
                 raw = y
                 continue
+            if tail:
+                return y, blk
             raw = None
             x = blk.norm_act(y)
-        return x
+        return (x, None) if raw_tail else x
 
     @staticmethod
     def _can_fuse(blk, nxt, inp):
@@ -285,7 +292,19 @@ class UNetDecoder(nn.Module):
         logits = []
         for level, (up, refine, head) in enumerate(zip(self.transpconvs, self.stages, self.seg_layers)):
             # the concatenation of (up-sampled, skip) is never materialised: the first conv reads both pointers
-            feat = refine(up(feat), skips[-(level + 2)])
+            head_l = head if self.deep_supervision else self.seg_layers[-1]
+            if (level == last and not return_last_feature and FUSE_SEGHEAD[0] and isinstance(refine, StackedConvBlocks)
+                    and getattr(refine.convs[-1], "precision", "fp32") == "bf16"):
+                # the top stage's output feeds the seg head alone: its last InstanceNorm + LeakyReLU ride in the head's loaders
+                y_raw, blk = refine(up(feat), skips[-(level + 2)], raw_tail=True)
+                if blk is not None and ops.fused_norm_seghead_ok(y_raw, head_l.weight):
+                    logits.append(ops.NormActSegHeadFn.apply(y_raw, blk.norm.weight, blk.norm.bias, blk.norm.eps,
+                                                             blk.nonlin.negative_slope, head_l.weight, head_l.bias))
+                    feat = None
+                    continue
+                feat = y_raw if blk is None else blk.norm_act(y_raw)
+            else:
+                feat = refine(up(feat), skips[-(level + 2)])
             if self.deep_supervision and level != last and SHARE_GRADS[0]:
                 ops.share_grad(feat)   # two consumers (this level's seg head, the next level's up-sampling): one gradient buffer
             if self.deep_supervision:

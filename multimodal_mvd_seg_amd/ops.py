@@ -980,6 +980,85 @@ class SegHeadFn(Function):
         return (None if joined is not None else dx), dw.view(ctx.wshape), db
 
 
+class NormActSegHeadFn(Function):
+    """The LAST decoder block's InstanceNorm3d + LeakyReLU folded into the seg head that is its only consumer (UNetDecoder.py:110
+    after get_network_from_plans.py:41-44; bf16): `y0` is the RAW output of the block's conv (with the statistics its epilogue
+    emitted attached), the head kernels apply a = bf16(lrelu(IN(y0))) in their loaders (mvd_seghead_*_bf16_fused) -- the
+    activated tensor of the top decoder stage is never written.  Backward: d a from the head's input-gradient kernel, the
+    InstanceNorm backward on (y0, d a), dW / db over the re-computed a.  Bit-identical to the two separate nodes."""
+
+    @staticmethod
+    def forward(ctx, y0, gamma, beta, eps, slope, weight, bias):
+        _require_cuda(y0, gamma, beta, weight, bias)
+        if not (_is_bf16(y0) and _is_cl3d(y0)):
+            raise RuntimeError("NormActSegHeadFn: needs the raw bf16 NDHWC conv output")
+        pre = getattr(y0, '_mvd_tile_stats16', None)
+        N, C, D, H, W = y0.shape
+        K = weight.shape[0]
+        V = D * H * W
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        mean = torch.empty((N, C), dtype=torch.float32, device=y0.device)
+        rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+        if pre is not None and pre[0].shape[0] == N and pre[0].shape[2] == C:
+            call("mvd_instnorm_finalize_tiles", _p(pre[0]), pre[1], _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N,
+                 V, C, float(eps), _stream())
+        else:
+            ws = _Workspace.get(query("mvd_instnorm_workspace_bytes", N, V, C), y0.device)
+            call("mvd_instnorm_stats_bf16", _p(y0), 1, _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N, V, C,
+                 float(eps), _p(ws), ws.numel(), _stream())
+        w = weight.detach().reshape(K, C).contiguous()
+        logits = torch.empty((N, K, D, H, W), dtype=torch.float32, device=y0.device)
+        call("mvd_seghead_fwd_bf16_fused", _p(y0), _p(scale), _p(shift), float(slope), _p(w), _p(bias), _p(logits), N, V, C, K,
+             _stream())
+        ctx.save_for_backward(y0, g, b, mean, rstd, scale, shift, w)
+        ctx.params = (gamma, beta)
+        ctx.slope = float(slope)
+        ctx.wshape = tuple(weight.shape)
+        return logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dl):
+        y0, g, b, mean, rstd, scale, shift, w = ctx.saved_tensors
+        gamma, beta = ctx.params
+        N, C, D, H, W = y0.shape
+        K = w.shape[0]
+        V = D * H * W
+        dev = y0.device
+        dl = dl.contiguous()
+        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        da = empty_cl3d(y0.shape, dev, BF16) if need_x else None
+        dw = torch.empty((K, C), dtype=torch.float32, device=dev)
+        db = torch.empty((K,), dtype=torch.float32, device=dev)
+        ws = _Workspace.get(query("mvd_seghead_bwd_workspace_bytes", N, V, C, K), dev)
+        call("mvd_seghead_bwd_bf16_fused", _p(y0), _p(scale), _p(shift), ctx.slope, _p(w), _p(dl), _p(da), _p(dw), _p(db), N, V,
+             C, K, 0, _p(ws), ws.numel(), _stream())
+        dy0 = dg = db_ = None
+        if need_x:
+            dy0 = empty_cl3d(y0.shape, dev, BF16)
+            sink_g, sink_b = _take_grad(gamma), _take_grad(beta)
+            dg = sink_g if sink_g is not None else torch.empty((C,), dtype=torch.float32, device=dev)
+            db_ = sink_b if sink_b is not None else torch.empty((C,), dtype=torch.float32, device=dev)
+            ws = _Workspace.get(query("mvd_instnorm_workspace_bytes", N, V, C), dev)
+            call("mvd_instnorm_lrelu_bwd_bf16", _p(y0), 1, _p(da), _p(g), _p(b), _p(mean), _p(rstd), _p(dy0), _p(dg), _p(db_),
+                 N, V, C, ctx.slope, _p(ws), ws.numel(), _stream())
+            if sink_g is not None:
+                dg = None
+                _grad_done(gamma)
+            if sink_b is not None:
+                db_ = None
+                _grad_done(beta)
+        return dy0, dg, db_, None, None, dw.view(ctx.wshape), db
+
+
+def fused_norm_seghead_ok(y0, weight):
+    """True when the seg head can read the raw bf16 conv output `y0` through its fused loaders."""
+    if not (_is_bf16(y0) and y0.dim() == 5 and _is_cl3d(y0) and y0.is_cuda):
+        return False
+    N, C = y0.shape[:2]
+    return weight.shape[1] == C and query("mvd_seghead_bf16_fused_ok", N, y0[0, 0].numel(), C, weight.shape[0]) > 0
+
+
 class CastFn(Function):
     """Precision boundary: bf16 activation -> fp32 (and the fp32 gradient back to bf16), layout preserved.  Used where
     a bf16 feature map feeds an fp32 loss kernel (the distillation features)."""

@@ -642,3 +642,66 @@ def test_round3_kernels_are_run_to_run_deterministic():
             y1.backward(gy)
             return [y1.detach(), yy.grad] + [p.grad for p in ps]
         same(fused, f"fused block {C} channels")
+
+
+@pytest.mark.parametrize("N,D,H,W", [(2, 64, 64, 64), (1, 33, 36, 44)])
+def test_norm_act_seghead_node_is_bit_identical_to_the_two_separate_nodes(N, D, H, W):
+    """ops.NormActSegHeadFn (the last decoder block's InstanceNorm + LeakyReLU inside the seg head's loaders, activated tensor
+    never written) against InstanceNormLeakyReLUFn -> SegHeadFn on the same raw conv output: logits, d y0, d gamma, d beta,
+    dW, db bit for bit."""
+    from multimodal_mvd_seg_amd import ops
+    g = torch.Generator().manual_seed(D + W)
+    y0 = (torch.randn(N, 32, D, H, W, generator=g) * 1.5 + 0.3).to(BF).to(DEV).contiguous(memory_format=CL)
+    gamma, beta = (torch.rand(32, generator=g) + 0.5).to(DEV), (torch.randn(32, generator=g) * 0.2).to(DEV)
+    w = (torch.randn(5, 32, 1, 1, 1, generator=g) * 0.2).to(DEV)
+    b = (torch.randn(5, generator=g) * 0.1).to(DEV)
+    gl = torch.randn(N, 5, D, H, W, generator=g).to(DEV)
+
+    def run(fused):
+        ps = [t.clone().requires_grad_() for t in (gamma, beta, w, b)]
+        yy = y0.clone().requires_grad_()
+        if fused:
+            lg = ops.NormActSegHeadFn.apply(yy, ps[0], ps[1], 1e-5, 0.01, ps[2], ps[3])
+        else:
+            lg = ops.SegHeadFn.apply(ops.InstanceNormLeakyReLUFn.apply(yy, ps[0], ps[1], 1e-5, 0.01, True), ps[2], ps[3])
+        lg.backward(gl)
+        return [lg.detach(), yy.grad] + [p.grad for p in ps]
+    assert ops.fused_norm_seghead_ok(y0, w)
+    for n, u, v in zip(["logits", "dy0", "dgamma", "dbeta", "dW", "db"], run(True), run(False)):
+        assert torch.equal(u, v), n
+
+
+def test_train_step_with_the_seg_head_fusion_is_bit_identical_and_it_runs():
+    from multimodal_mvd_seg_amd import network, trainer
+    strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
+    plans = trainer.make_plans((64, 64, 64), strides, batch_size=2)
+    ds = {"channel_names": {str(i): f"m{i}" for i in range(4)}, "labels": {"background": 0, "a": 1, "b": 2, "c": 3, "d": 4}}
+    res, counts = [], {}
+    saved = network.FUSE_SEGHEAD[0]
+    try:
+        for mode in (True, False):
+            network.FUSE_SEGHEAD[0] = mode
+            tr = trainer.nnUNetTrainerMI355(plans, "3d_fullres", 0, ds, device=DEV)
+            tr.precision = "bf16"
+            tr.use_hip_graph = False
+            torch.manual_seed(0)
+            tr.initialize()
+            n_fused = [0]
+            orig_call = network.ops.call
+
+            def counting_call(name, *a, **k):
+                n_fused[0] += name == "mvd_seghead_fwd_bf16_fused"
+                return orig_call(name, *a, **k)
+            network.ops.call = counting_call
+            try:
+                losses = [float(tr.train_step(tr.make_dummy_batch(seed=9 + i))["loss"]) for i in range(2)]
+            finally:
+                network.ops.call = orig_call
+            counts[mode] = n_fused[0]
+            res.append((losses, [p.detach().clone() for p in tr.network.parameters()]))
+    finally:
+        network.FUSE_SEGHEAD[0] = saved
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for p, q in zip(res[0][1], res[1][1]):
+        assert torch.equal(p, q)
+    assert counts[True] == 2 and counts[False] == 0, counts
