@@ -222,6 +222,16 @@ int mvd_seghead_bwd_bf16(const uint16_t *x, const float *w, const float *dlogits
  * tensor is not materialised.  _bwd: dx = d a (the caller runs the InstanceNorm backward on it), dw / dbias over the
  * re-computed a.  Bit-identical to mvd_seghead_*_bf16 over the tensor mvd_instnorm_lrelu_apply_bf16 would write. */
 int mvd_seghead_bf16_fused_ok(int N, long V, int C, int K);
+/* fp32 twins (mean / rstd / gamma / beta: the arithmetic of the fp32 apply pass); same eligibility query */
+int mvd_seghead_fwd_fused(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
+                          const float *w, const float *bias, float *logits, int N, long V, int C, int K, void *stream);
+int mvd_seghead_bwd_fused(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
+                          const float *w, const float *dlogits, float *dx, float *dw, float *dbias, int N, long V, int C, int K,
+                          int accumulate, void *ws, size_t ws_bytes, void *stream);
+/* mean / rstd from the fp32 conv epilogue's tile statistics without the apply pass (the first half of
+ * mvd_instnorm_lrelu_fwd_prestats) */
+int mvd_instnorm_stats_from_tiles(const float *tile_stats, long ntiles, float *mean, float *rstd, int N, long V, int C, float eps,
+                                  void *ws, size_t ws_bytes, void *stream);
 int mvd_seghead_fwd_bf16_fused(const uint16_t *x, const float *scale, const float *shift, float slope, const float *w,
                                const float *bias, float *logits, int N, long V, int C, int K, void *stream);
 int mvd_seghead_bwd_bf16_fused(const uint16_t *x, const float *scale, const float *shift, float slope, const float *w,

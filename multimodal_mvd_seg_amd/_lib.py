@@ -73,6 +73,10 @@ SIGNATURES = {
     "mvd_seghead_fwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_long, c_int, c_int, _P]),
     "mvd_seghead_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_int, c_int, _P, c_size_t, _P]),
     "mvd_seghead_bf16_fused_ok": (c_int, [c_int, c_long, c_int, c_int]),
+    "mvd_seghead_fwd_fused": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_long, c_int, c_int, _P]),
+    "mvd_seghead_bwd_fused": (c_int, [_P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_int, c_int, _P,
+                                      c_size_t, _P]),
+    "mvd_instnorm_stats_from_tiles": (c_int, [_P, c_long, _P, _P, c_int, c_long, c_int, c_float, _P, c_size_t, _P]),
     "mvd_seghead_fwd_bf16_fused": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_long, c_int, c_int, _P]),
     "mvd_seghead_bwd_bf16_fused": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_long, c_int, c_int, c_int, _P,
                                            c_size_t, _P]),

@@ -205,13 +205,13 @@ __global__ void k_in_apply(const float *__restrict__ x, const float *__restrict_
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 float xh = (f[k] - mean[(size_t)n * C + c + k]) * rstd[(size_t)n * C + c + k];
-                float z = xh * gamma[c + k] + beta[c + k];
+                float z = fmaf(xh, gamma[c + k], beta[c + k]);
                 f[k] = z > 0.f ? z : z * slope;
             }
             reinterpret_cast<float4 *>(yn)[i] = make_float4(f[0], f[1], f[2], f[3]);
         } else {
             float xh = (xn[i] - mean[(size_t)n * C + c]) * rstd[(size_t)n * C + c];
-            float z = xh * gamma[c] + beta[c];
+            float z = fmaf(xh, gamma[c], beta[c]);
             yn[i] = z > 0.f ? z : z * slope;
         }
     }
@@ -251,7 +251,7 @@ __global__ void k_in_apply_rows(const float *__restrict__ x, const float *__rest
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float xh = (f[i] - mu[i]) * rs[i];
-                const float z = xh * ga[i] + be[i];
+                const float z = fmaf(xh, ga[i], be[i]);  // (explicit: the same rounding in every kernel that re-computes z)
                 f[i] = z > 0.f ? z : z * slope;
             }
             st4<YB>(y, base + (size_t)(v + (long)u * R) * C, f[0], f[1], f[2], f[3]);
@@ -263,7 +263,7 @@ __global__ void k_in_apply_rows(const float *__restrict__ x, const float *__rest
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float xh = (f[i] - mu[i]) * rs[i];
-            const float z = xh * ga[i] + be[i];
+            const float z = fmaf(xh, ga[i], be[i]);  // (explicit: the same rounding in every kernel that re-computes z)
             f[i] = z > 0.f ? z : z * slope;
         }
         st4<YB>(y, base + (size_t)v * C, f[0], f[1], f[2], f[3]);
@@ -314,7 +314,7 @@ __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const float xh = (f[i] - mu[i]) * rs[i];
-                const float z = xh * ga[i] + be[i];
+                const float z = fmaf(xh, ga[i], be[i]);  // (explicit: the same rounding in every kernel that re-computes z)
                 const float dz = z > 0.f ? d[i] : d[i] * slope;
                 f[i] = ga[i] * rs[i] * (dz - m1[i] - xh * m2[i]);
             }
@@ -328,7 +328,7 @@ __global__ void k_in_bwd_apply_rows(const float *__restrict__ x, const float *__
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float xh = (f[i] - mu[i]) * rs[i];
-            const float z = xh * ga[i] + be[i];
+            const float z = fmaf(xh, ga[i], be[i]);  // (explicit: the same rounding in every kernel that re-computes z)
             const float dz = z > 0.f ? d[i] : d[i] * slope;
             f[i] = ga[i] * rs[i] * (dz - m1[i] - xh * m2[i]);
         }
@@ -375,7 +375,7 @@ __global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restr
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const float xh = (fx[u][i] - mu[i]) * rs[i];
-                        const float z = xh * ga[i] + be[i];
+                        const float z = fmaf(xh, ga[i], be[i]);  // (explicit: the same rounding in every kernel that re-computes z)
                         const float dz = z > 0.f ? dd[u][i] : dd[u][i] * slope;
                         s[i] += (double)dz;
                         ss[i] += (double)dz * (double)xh;
@@ -396,7 +396,7 @@ __global__ void k_in_bwd_stats(const float *__restrict__ x, const float *__restr
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
                 float xh = (f[i] - mu[i]) * rs[i];
-                float z = xh * ga[i] + be[i];
+                float z = fmaf(xh, ga[i], be[i]);
                 float dz = z > 0.f ? d[i] : d[i] * slope;
                 s[i] += (double)dz;
                 ss[i] += (double)dz * (double)xh;
@@ -568,7 +568,7 @@ __global__ void k_in_bwd_apply(const float *__restrict__ x, const float *__restr
             size_t nc = (size_t)n * C + c + k;
             float rs = rstd[nc];
             float xh = (f[k] - mean[nc]) * rs;
-            float z = xh * gamma[c + k] + beta[c + k];
+            float z = fmaf(xh, gamma[c + k], beta[c + k]);
             float dz = z > 0.f ? d[k] : d[k] * slope;
             float m1 = sums[nc * 2 + 0] * invV, m2 = sums[nc * 2 + 1] * invV;
             f[k] = gamma[c + k] * rs * (dz - m1 - xh * m2);
@@ -776,6 +776,29 @@ int mvd_instnorm_stats_bf16(const void *x, int x_is_bf16, const float *gamma, co
         hipLaunchKernelGGL((k_in_stats<4, false>), dim3(g.nblk, N), dim3(g.threads), sm, s, xf, partial, C, g.CG, g.R, V, g.chunk);
     if (check_launch("instnorm stats")) return 1;
     hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, g.nblk, V, eps, gamma, beta, scale, shift);
+    return check_launch("instnorm finalize");
+}
+
+// mean / rstd of an fp32 tensor from the fp32 conv's epilogue tiles (the statistics half of mvd_instnorm_lrelu_fwd_prestats:
+// same launches, same order -- no apply pass; ops.NormActSegHeadFn in fp32)
+int mvd_instnorm_stats_from_tiles(const float *tile_stats, long ntiles, float *mean, float *rstd, int N, long V, int C, float eps,
+                                  void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(tile_stats && ntiles > 0 && mean && rstd && ws, "instnorm_stats_from_tiles: bad arguments");
+    MVD_REQUIRE(N > 0 && N <= 65535 && V > 0 && C > 0 && C <= 1024, "instnorm_stats_from_tiles: bad shape");
+    MVD_REQUIRE(ws_bytes >= mvd_instnorm_workspace_bytes(N, V, C), "instnorm_stats_from_tiles: workspace too small");
+    NormGeom g = norm_geom(N, V, C);
+    hipStream_t s = as_stream(stream);
+    double *partial = reinterpret_cast<double *>(ws);
+    long nb2 = (ntiles + 63) / 64;
+    if (nb2 > g.nblk) nb2 = g.nblk;
+    if (nb2 > 64) nb2 = 64;
+    const long chunk2 = (ntiles + nb2 - 1) / nb2;
+    nb2 = (ntiles + chunk2 - 1) / chunk2;
+    const int CW = C < 256 ? C : 256, R2 = 256 / CW;
+    hipLaunchKernelGGL(k_in_tiles_reduce, dim3((unsigned)nb2, N), dim3(256), (size_t)R2 * CW * 2 * sizeof(double), s, tile_stats,
+                       partial, C, CW, R2, ntiles, chunk2);
+    if (check_launch("instnorm statistics from conv tiles")) return 1;
+    hipLaunchKernelGGL(k_in_finalize, dim3(C, N), dim3(64), 0, s, partial, mean, rstd, C, (int)nb2, V, eps);
     return check_launch("instnorm finalize");
 }
 

@@ -92,11 +92,25 @@ __device__ inline float4 seg_pro4(float4 q, const float *__restrict__ sc, const 
     }
     return make_float4(f[0], f[1], f[2], f[3]);
 }
-template <bool XB, bool PRO = false>
+// fp32 form (PRO = 2): the expression of k_in_apply_rows<false, false> -- ((x - mean) * rstd) * gamma + beta, z > 0 ? z : z * slope
+__device__ inline float4 seg_pro4f(float4 q, const float *__restrict__ mu, const float *__restrict__ rs,
+                                   const float *__restrict__ ga, const float *__restrict__ be, float slope) {
+    float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float xh = (f[i] - mu[i]) * rs[i];
+        const float z = fmaf(xh, ga[i], be[i]);  // (explicit: the same rounding in every kernel that re-computes z)
+        f[i] = z > 0.f ? z : z * slope;
+    }
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+template <bool XB, int PRO = 0>
 __global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict__ x, const float *__restrict__ w,
                                                          const float *__restrict__ bias, float *__restrict__ logits, long V,
                                                          int C, int K, const float *__restrict__ scale = nullptr,
-                                                         const float *__restrict__ shift = nullptr, float slope = 0.f) {
+                                                         const float *__restrict__ shift = nullptr, float slope = 0.f,
+                                                         const float *__restrict__ gamma = nullptr,
+                                                         const float *__restrict__ beta = nullptr) {
     const int n = blockIdx.y;
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
@@ -111,10 +125,16 @@ __global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict
         if (full) {
 #pragma unroll
             for (int j = 0; j < 8; j++) q[j] = ld4<XB>(x, xo + c0 + 4 * j);
-            if (PRO) {   // (host: C % 32 == 0) scale / shift of sample n: wave-uniform, scalar loads
+            if (PRO == 1) {   // (host: C % 32 == 0) scale / shift of sample n: wave-uniform, scalar loads
 #pragma unroll
                 for (int j = 0; j < 8; j++)
                     q[j] = seg_pro4(q[j], scale + (size_t)n * C + c0 + 4 * j, shift + (size_t)n * C + c0 + 4 * j, slope);
+            }
+            if (PRO == 2) {   // fp32: scale = mean, shift = rstd of sample n
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    q[j] = seg_pro4f(q[j], scale + (size_t)n * C + c0 + 4 * j, shift + (size_t)n * C + c0 + 4 * j, gamma + c0 + 4 * j,
+                                     beta + c0 + 4 * j, slope);
             }
         } else {
 #pragma unroll
@@ -128,10 +148,10 @@ __global__ __launch_bounds__(256) void k_seghead_fwd_vox(const float *__restrict
 #pragma unroll
                 for (int j = 0; j < 8; j++)
                     if (c0 + 4 * j < C) {
-                        a += q[j].x * wk[4 * j];
-                        a += q[j].y * wk[4 * j + 1];
-                        a += q[j].z * wk[4 * j + 2];
-                        a += q[j].w * wk[4 * j + 3];
+                        a = fmaf(q[j].x, wk[4 * j], a);
+                        a = fmaf(q[j].y, wk[4 * j + 1], a);
+                        a = fmaf(q[j].z, wk[4 * j + 2], a);
+                        a = fmaf(q[j].w, wk[4 * j + 3], a);
                     }
                 acc[k] = a;
             }
@@ -345,10 +365,11 @@ __global__ void k_seghead_dw4(const float *__restrict__ x, const float *__restri
 
 // V % 4 == 0 variant: a thread walks QUADS of consecutive voxels, so the planar dlogits come in as one float4 per
 // class (instead of 4 scalar loads) next to the 4 channel rows; no per-voxel division (n, v advance incrementally)
-template <bool XB, bool PRO = false>
+template <bool XB, int PRO = 0>
 __global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restrict__ dl, double *__restrict__ partial,
                                int N, long V, int C, int K, long chunk, const float *__restrict__ scale = nullptr,
-                               const float *__restrict__ shift = nullptr, float slope = 0.f) {
+                               const float *__restrict__ shift = nullptr, float slope = 0.f,
+                               const float *__restrict__ gamma = nullptr, const float *__restrict__ beta = nullptr) {
     extern __shared__ float smf[];  // [R][K*C + K]
     const int t = threadIdx.x;
     const int CG = C / 4, R = blockDim.x / CG;
@@ -376,8 +397,15 @@ __global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restr
             if (PRO) {   // the four voxels i .. i + 3 belong to one sample (V % 4 == 0): its scale / shift of this lane's channels
                 const float *sc = scale + (size_t)n * C + g * 4, *sh = shift + (size_t)n * C + g * 4;
                 const float s4[4] = {sc[0], sc[1], sc[2], sc[3]}, h4[4] = {sh[0], sh[1], sh[2], sh[3]};
+                if (PRO == 1) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) q[u] = seg_pro4(q[u], s4, h4, slope);
+                    for (int u = 0; u < 4; u++) q[u] = seg_pro4(q[u], s4, h4, slope);
+                } else {   // fp32: (mean, rstd) of the sample, gamma / beta of the channels
+                    const float g4[4] = {gamma[g * 4], gamma[g * 4 + 1], gamma[g * 4 + 2], gamma[g * 4 + 3]};
+                    const float b4[4] = {beta[g * 4], beta[g * 4 + 1], beta[g * 4 + 2], beta[g * 4 + 3]};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) q[u] = seg_pro4f(q[u], s4, h4, g4, b4, slope);
+                }
             }
             float4 dq[KMAX];  // (all classes in flight at once, see k_seghead_dx4)
 #pragma unroll
@@ -387,10 +415,12 @@ __global__ void k_seghead_dw4v(const float *__restrict__ x, const float *__restr
             for (int k = 0; k < KMAX; k++)
                 if (k < K) {
                     const float4 d = dq[k];
-                    acc[k][0] += d.x * q[0].x + d.y * q[1].x + d.z * q[2].x + d.w * q[3].x;
-                    acc[k][1] += d.x * q[0].y + d.y * q[1].y + d.z * q[2].y + d.w * q[3].y;
-                    acc[k][2] += d.x * q[0].z + d.y * q[1].z + d.z * q[2].z + d.w * q[3].z;
-                    acc[k][3] += d.x * q[0].w + d.y * q[1].w + d.z * q[2].w + d.w * q[3].w;
+                    // (explicit fma chains: the contraction the compiler picks otherwise differs between the instantiations of
+                    // this kernel -- with and without the loader prologue -- and with it the last bit of dW)
+                    acc[k][0] = fmaf(d.w, q[3].x, fmaf(d.z, q[2].x, fmaf(d.y, q[1].x, fmaf(d.x, q[0].x, acc[k][0]))));
+                    acc[k][1] = fmaf(d.w, q[3].y, fmaf(d.z, q[2].y, fmaf(d.y, q[1].y, fmaf(d.x, q[0].y, acc[k][1]))));
+                    acc[k][2] = fmaf(d.w, q[3].z, fmaf(d.z, q[2].z, fmaf(d.y, q[1].z, fmaf(d.x, q[0].z, acc[k][2]))));
+                    acc[k][3] = fmaf(d.w, q[3].w, fmaf(d.z, q[2].w, fmaf(d.y, q[1].w, fmaf(d.x, q[0].w, acc[k][3]))));
                     accb[k] += (d.x + d.y) + (d.z + d.w);
                 }
             v += step;
@@ -875,7 +905,7 @@ static int seghead_fwd_impl(const float *x, bool xb, const float *w, const float
     if (C % 4 == 0 && (((uintptr_t)x) & 15) == 0) {
         auto kv = xb ? k_seghead_fwd_vox<true> : k_seghead_fwd_vox<false>;
         hipLaunchKernelGGL(kv, dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C, K,
-                           (const float *)nullptr, (const float *)nullptr, 0.f);
+                           (const float *)nullptr, (const float *)nullptr, 0.f, (const float *)nullptr, (const float *)nullptr);
         return check_launch("seghead_fwd");
     }
     auto kern = xb ? k_seghead_fwd<true> : k_seghead_fwd<false>;
@@ -942,7 +972,8 @@ static int seghead_bwd_impl(const float *x, bool xb, const float *w, const float
         const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
         if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0 && V % 4 == 0 && (((uintptr_t)dlogits) & 15) == 0)
             hipLaunchKernelGGL(xb ? k_seghead_dw4v<true> : k_seghead_dw4v<false>, dim3(nblk), dim3((R * CG + 63) / 64 * 64),
-                               smb, s, x, dlogits, partial, N, V, C, K, chunk, (const float *)nullptr, (const float *)nullptr, 0.f);
+                               smb, s, x, dlogits, partial, N, V, C, K, chunk, (const float *)nullptr, (const float *)nullptr, 0.f,
+                               (const float *)nullptr, (const float *)nullptr);
         else if (R >= 1 && smb <= 60 * 1024 && (((uintptr_t)x) & 15) == 0)
             hipLaunchKernelGGL(xb ? k_seghead_dw4<true> : k_seghead_dw4<false>, dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s, x, dlogits, partial, N, V,
                                C, K, chunk);
@@ -978,8 +1009,9 @@ int mvd_seghead_fwd_bf16_fused(const uint16_t *x, const float *scale, const floa
     MVD_REQUIRE(x && scale && shift && w && bias && logits, "seghead_fwd_bf16_fused: null pointer");
     MVD_REQUIRE(mvd_seghead_bf16_fused_ok(N, V, C, K) && (((uintptr_t)x) & 15) == 0,
                 "seghead_fwd_bf16_fused: shape not served (query mvd_seghead_bf16_fused_ok)");
-    hipLaunchKernelGGL((k_seghead_fwd_vox<true, true>), dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float *>(x), w, bias, logits, V, C, K, scale, shift, slope);
+    hipLaunchKernelGGL((k_seghead_fwd_vox<true, 1>), dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float *>(x), w, bias, logits, V, C, K, scale, shift, slope, (const float *)nullptr,
+                       (const float *)nullptr);
     return check_launch("seghead_fwd (fused InstanceNorm + LeakyReLU loader)");
 }
 
@@ -1008,9 +1040,53 @@ int mvd_seghead_bwd_bf16_fused(const uint16_t *x, const float *scale, const floa
         double *partial = reinterpret_cast<double *>(ws);
         const int CG = C / 4, R = 256 / CG;
         const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
-        hipLaunchKernelGGL((k_seghead_dw4v<true, true>), dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s,
-                           reinterpret_cast<const float *>(x), dlogits, partial, N, V, C, K, chunk, scale, shift, slope);
+        hipLaunchKernelGGL((k_seghead_dw4v<true, 1>), dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s,
+                           reinterpret_cast<const float *>(x), dlogits, partial, N, V, C, K, chunk, scale, shift, slope,
+                           (const float *)nullptr, (const float *)nullptr);
         if (check_launch("seghead_dw (fused loader)")) return 1;
+        if (reduce_partials(partial, dw, nblk, K * C, s, K * C + K, 0)) return 1;
+        if (reduce_partials(partial, dbias, nblk, K, s, K * C + K, K * C)) return 1;
+    }
+    return 0;
+}
+
+// fp32 twins: mean / rstd / gamma / beta instead of scale / shift (the arithmetic of the fp32 apply pass)
+int mvd_seghead_fwd_fused(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
+                          const float *w, const float *bias, float *logits, int N, long V, int C, int K, void *stream) {
+    MVD_REQUIRE(x && mean && rstd && gamma && beta && w && bias && logits, "seghead_fwd_fused: null pointer");
+    MVD_REQUIRE(mvd_seghead_bf16_fused_ok(N, V, C, K) && (((uintptr_t)x) & 15) == 0,
+                "seghead_fwd_fused: shape not served (query mvd_seghead_bf16_fused_ok)");
+    hipLaunchKernelGGL((k_seghead_fwd_vox<false, 2>), dim3(cdiv(V, 256), N), dim3(256), 0, as_stream(stream), x, w, bias, logits, V, C,
+                       K, mean, rstd, slope, gamma, beta);
+    return check_launch("seghead_fwd (fused InstanceNorm + LeakyReLU loader, fp32)");
+}
+
+int mvd_seghead_bwd_fused(const float *x, const float *mean, const float *rstd, const float *gamma, const float *beta, float slope,
+                          const float *w, const float *dlogits, float *dx, float *dw, float *dbias, int N, long V, int C, int K,
+                          int accumulate, void *ws, size_t ws_bytes, void *stream) {
+    MVD_REQUIRE(x && mean && rstd && gamma && beta && w && dlogits && ws, "seghead_bwd_fused: null pointer");
+    MVD_REQUIRE(mvd_seghead_bf16_fused_ok(N, V, C, K) && (((uintptr_t)x | (uintptr_t)dlogits | (uintptr_t)w) & 15) == 0,
+                "seghead_bwd_fused: shape not served (query mvd_seghead_bf16_fused_ok)");
+    MVD_REQUIRE(ws_bytes >= mvd_seghead_bwd_workspace_bytes(N, V, C, K), "seghead_bwd_fused: workspace too small");
+    hipStream_t s = as_stream(stream);
+    if (dx) {
+        MVD_REQUIRE((((uintptr_t)dx) & 15) == 0, "seghead_bwd_fused: dx alignment");
+        const long R = 256 / (C / 4);
+        long nb = cdiv(V / 4, R);
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(k_seghead_dx4<false>, dim3((unsigned)nb, N), dim3(256), 0, s, dlogits, w, dx, V, C, K, accumulate);
+        if (check_launch("seghead_dx")) return 1;
+    }
+    if (dw) {
+        MVD_REQUIRE(dbias, "seghead_bwd_fused: dbias required with dw");
+        int nblk;
+        long chunk = seghead_chunk((long)N * V, &nblk);
+        double *partial = reinterpret_cast<double *>(ws);
+        const int CG = C / 4, R = 256 / CG;
+        const size_t smb = (size_t)R * (K * C + K) * sizeof(float);
+        hipLaunchKernelGGL((k_seghead_dw4v<false, 2>), dim3(nblk), dim3((R * CG + 63) / 64 * 64), smb, s, x, dlogits, partial, N, V, C,
+                           K, chunk, mean, rstd, slope, gamma, beta);
+        if (check_launch("seghead_dw (fused loader, fp32)")) return 1;
         if (reduce_partials(partial, dw, nblk, K * C, s, K * C + K, 0)) return 1;
         if (reduce_partials(partial, dbias, nblk, K, s, K * C + K, K * C)) return 1;
     }

@@ -156,7 +156,7 @@ class StackedConvBlocks(nn.Module):
         for i, blk in enumerate(blocks):
             nxt = blocks[i + 1] if i + 1 < len(blocks) else None
             fuse_next = nxt is not None and self._can_fuse(blk, nxt, x if raw is None else raw)
-            tail = raw_tail and nxt is None and blk.precision == "bf16" and FUSE_PROLOGUE[0]
+            tail = raw_tail and nxt is None and FUSE_PROLOGUE[0]
             if raw is None and not fuse_next and not tail:
                 x = blk(x, x2) if i == 0 else blk(x)      # the plain module call (forward hooks fire)
                 continue
@@ -293,8 +293,7 @@ class UNetDecoder(nn.Module):
         for level, (up, refine, head) in enumerate(zip(self.transpconvs, self.stages, self.seg_layers)):
             # the concatenation of (up-sampled, skip) is never materialised: the first conv reads both pointers
             head_l = head if self.deep_supervision else self.seg_layers[-1]
-            if (level == last and not return_last_feature and FUSE_SEGHEAD[0] and isinstance(refine, StackedConvBlocks)
-                    and getattr(refine.convs[-1], "precision", "fp32") == "bf16"):
+            if level == last and not return_last_feature and FUSE_SEGHEAD[0] and isinstance(refine, StackedConvBlocks):
                 # the top stage's output feeds the seg head alone: its last InstanceNorm + LeakyReLU ride in the head's loaders
                 y_raw, blk = refine(up(feat), skips[-(level + 2)], raw_tail=True)
                 if blk is not None and ops.fused_norm_seghead_ok(y_raw, head_l.weight):

@@ -982,34 +982,45 @@ class SegHeadFn(Function):
 
 class NormActSegHeadFn(Function):
     """The LAST decoder block's InstanceNorm3d + LeakyReLU folded into the seg head that is its only consumer (UNetDecoder.py:110
-    after get_network_from_plans.py:41-44; bf16): `y0` is the RAW output of the block's conv (with the statistics its epilogue
-    emitted attached), the head kernels apply a = bf16(lrelu(IN(y0))) in their loaders (mvd_seghead_*_bf16_fused) -- the
-    activated tensor of the top decoder stage is never written.  Backward: d a from the head's input-gradient kernel, the
-    InstanceNorm backward on (y0, d a), dW / db over the re-computed a.  Bit-identical to the two separate nodes."""
+    after get_network_from_plans.py:41-44): `y0` is the RAW output of the block's conv (with the statistics its epilogue
+    emitted attached), the head kernels apply the normalisation + activation in their loaders (mvd_seghead_*_fused: bf16 in the
+    scale / shift form of the bf16 apply pass, fp32 in the mean / rstd form of the fp32 one) -- the activated tensor of the
+    top decoder stage is never written.  Backward: d a from the head's input-gradient kernel, the InstanceNorm backward on
+    (y0, d a), dW / db over the re-computed a.  Bit-identical to the two separate nodes."""
 
     @staticmethod
     def forward(ctx, y0, gamma, beta, eps, slope, weight, bias):
         _require_cuda(y0, gamma, beta, weight, bias)
-        if not (_is_bf16(y0) and _is_cl3d(y0)):
-            raise RuntimeError("NormActSegHeadFn: needs the raw bf16 NDHWC conv output")
-        pre = getattr(y0, '_mvd_tile_stats16', None)
+        bf = _is_bf16(y0)
+        if not _is_cl3d(y0) or y0.dtype not in (BF16, torch.float32):
+            raise RuntimeError("NormActSegHeadFn: needs the raw NDHWC conv output (bf16 or fp32)")
         N, C, D, H, W = y0.shape
         K = weight.shape[0]
         V = D * H * W
+        dev = y0.device
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        mean = torch.empty((N, C), dtype=torch.float32, device=y0.device)
+        mean = torch.empty((N, C), dtype=torch.float32, device=dev)
         rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
-        if pre is not None and pre[0].shape[0] == N and pre[0].shape[2] == C:
-            call("mvd_instnorm_finalize_tiles", _p(pre[0]), pre[1], _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N,
+        ws = _Workspace.get(query("mvd_instnorm_workspace_bytes", N, V, C), dev)
+        pre16 = getattr(y0, '_mvd_tile_stats16', None) if bf else None
+        pre = getattr(y0, '_mvd_tile_stats', None) if not bf else None
+        if pre16 is not None and pre16[0].shape[0] == N and pre16[0].shape[2] == C:
+            call("mvd_instnorm_finalize_tiles", _p(pre16[0]), pre16[1], _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N,
                  V, C, float(eps), _stream())
+        elif pre is not None and pre[0].shape[0] == N and pre[0].shape[2] == C:
+            call("mvd_instnorm_stats_from_tiles", _p(pre[0]), pre[1], _p(mean), _p(rstd), N, V, C, float(eps), _p(ws), ws.numel(),
+                 _stream())
         else:
-            ws = _Workspace.get(query("mvd_instnorm_workspace_bytes", N, V, C), y0.device)
-            call("mvd_instnorm_stats_bf16", _p(y0), 1, _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N, V, C,
+            call("mvd_instnorm_stats_bf16", _p(y0), int(bf), _p(g), _p(b), _p(mean), _p(rstd), _p(scale), _p(shift), N, V, C,
                  float(eps), _p(ws), ws.numel(), _stream())
         w = weight.detach().reshape(K, C).contiguous()
-        logits = torch.empty((N, K, D, H, W), dtype=torch.float32, device=y0.device)
-        call("mvd_seghead_fwd_bf16_fused", _p(y0), _p(scale), _p(shift), float(slope), _p(w), _p(bias), _p(logits), N, V, C, K,
-             _stream())
+        logits = torch.empty((N, K, D, H, W), dtype=torch.float32, device=dev)
+        if bf:
+            call("mvd_seghead_fwd_bf16_fused", _p(y0), _p(scale), _p(shift), float(slope), _p(w), _p(bias), _p(logits), N, V, C,
+                 K, _stream())
+        else:
+            call("mvd_seghead_fwd_fused", _p(y0), _p(mean), _p(rstd), _p(g), _p(b), float(slope), _p(w), _p(bias), _p(logits), N,
+                 V, C, K, _stream())
         ctx.save_for_backward(y0, g, b, mean, rstd, scale, shift, w)
         ctx.params = (gamma, beta)
         ctx.slope = float(slope)
@@ -1021,27 +1032,36 @@ class NormActSegHeadFn(Function):
     def backward(ctx, dl):
         y0, g, b, mean, rstd, scale, shift, w = ctx.saved_tensors
         gamma, beta = ctx.params
+        bf = _is_bf16(y0)
         N, C, D, H, W = y0.shape
         K = w.shape[0]
         V = D * H * W
         dev = y0.device
         dl = dl.contiguous()
         need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        da = empty_cl3d(y0.shape, dev, BF16) if need_x else None
+        da = empty_cl3d(y0.shape, dev, y0.dtype) if need_x else None
         dw = torch.empty((K, C), dtype=torch.float32, device=dev)
         db = torch.empty((K,), dtype=torch.float32, device=dev)
         ws = _Workspace.get(query("mvd_seghead_bwd_workspace_bytes", N, V, C, K), dev)
-        call("mvd_seghead_bwd_bf16_fused", _p(y0), _p(scale), _p(shift), ctx.slope, _p(w), _p(dl), _p(da), _p(dw), _p(db), N, V,
-             C, K, 0, _p(ws), ws.numel(), _stream())
+        if bf:
+            call("mvd_seghead_bwd_bf16_fused", _p(y0), _p(scale), _p(shift), ctx.slope, _p(w), _p(dl), _p(da), _p(dw), _p(db), N,
+                 V, C, K, 0, _p(ws), ws.numel(), _stream())
+        else:
+            call("mvd_seghead_bwd_fused", _p(y0), _p(mean), _p(rstd), _p(g), _p(b), ctx.slope, _p(w), _p(dl), _p(da), _p(dw),
+                 _p(db), N, V, C, K, 0, _p(ws), ws.numel(), _stream())
         dy0 = dg = db_ = None
         if need_x:
-            dy0 = empty_cl3d(y0.shape, dev, BF16)
+            dy0 = empty_cl3d(y0.shape, dev, y0.dtype)
             sink_g, sink_b = _take_grad(gamma), _take_grad(beta)
             dg = sink_g if sink_g is not None else torch.empty((C,), dtype=torch.float32, device=dev)
             db_ = sink_b if sink_b is not None else torch.empty((C,), dtype=torch.float32, device=dev)
             ws = _Workspace.get(query("mvd_instnorm_workspace_bytes", N, V, C), dev)
-            call("mvd_instnorm_lrelu_bwd_bf16", _p(y0), 1, _p(da), _p(g), _p(b), _p(mean), _p(rstd), _p(dy0), _p(dg), _p(db_),
-                 N, V, C, ctx.slope, _p(ws), ws.numel(), _stream())
+            if bf:
+                call("mvd_instnorm_lrelu_bwd_bf16", _p(y0), 1, _p(da), _p(g), _p(b), _p(mean), _p(rstd), _p(dy0), _p(dg),
+                     _p(db_), N, V, C, ctx.slope, _p(ws), ws.numel(), _stream())
+            else:
+                call("mvd_instnorm_lrelu_bwd", _p(y0), _p(da), _p(g), _p(b), _p(mean), _p(rstd), _p(dy0), _p(dg), _p(db_), N, V,
+                     C, ctx.slope, _p(ws), ws.numel(), _stream())
             if sink_g is not None:
                 dg = None
                 _grad_done(gamma)
@@ -1052,8 +1072,8 @@ class NormActSegHeadFn(Function):
 
 
 def fused_norm_seghead_ok(y0, weight):
-    """True when the seg head can read the raw bf16 conv output `y0` through its fused loaders."""
-    if not (_is_bf16(y0) and y0.dim() == 5 and _is_cl3d(y0) and y0.is_cuda):
+    """True when the seg head can read the raw (bf16 or fp32) conv output `y0` through its fused loaders."""
+    if not (y0.dtype in (BF16, torch.float32) and y0.dim() == 5 and _is_cl3d(y0) and y0.is_cuda):
         return False
     N, C = y0.shape[:2]
     return weight.shape[1] == C and query("mvd_seghead_bf16_fused_ok", N, y0[0, 0].numel(), C, weight.shape[0]) > 0

@@ -448,7 +448,13 @@ def test_cfg2_network_gradients_vs_fp64_truth():
             hooks.append(m.register_forward_hook(
                 lambda mod, inp, out, n=n: masks.__setitem__(n, (out.detach() > 0).cpu().contiguous())))
     tr.optimizer.zero_grad()
-    tr.loss(tr.network(batch["data"].to(DEV)), [t.to(DEV) for t in batch["target"]]).backward()
+    from multimodal_mvd_seg_amd import network as _net
+    seg_fuse = _net.FUSE_SEGHEAD[0]
+    _net.FUSE_SEGHEAD[0] = False   # the hooks need every block's ACTIVATED output: the last block's exists only un-fused
+    try:                           # (round 3: its norm + act otherwise run inside the seg head's loaders; same arithmetic)
+        tr.loss(tr.network(batch["data"].to(DEV)), [t.to(DEV) for t in batch["target"]]).backward()
+    finally:
+        _net.FUSE_SEGHEAD[0] = seg_fuse
     for h in hooks:
         h.remove()
     assert len(masks) == 22

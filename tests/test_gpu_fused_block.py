@@ -644,14 +644,16 @@ def test_round3_kernels_are_run_to_run_deterministic():
         same(fused, f"fused block {C} channels")
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
 @pytest.mark.parametrize("N,D,H,W", [(2, 64, 64, 64), (1, 33, 36, 44)])
-def test_norm_act_seghead_node_is_bit_identical_to_the_two_separate_nodes(N, D, H, W):
+def test_norm_act_seghead_node_is_bit_identical_to_the_two_separate_nodes(N, D, H, W, dt):
     """ops.NormActSegHeadFn (the last decoder block's InstanceNorm + LeakyReLU inside the seg head's loaders, activated tensor
     never written) against InstanceNormLeakyReLUFn -> SegHeadFn on the same raw conv output: logits, d y0, d gamma, d beta,
     dW, db bit for bit."""
     from multimodal_mvd_seg_amd import ops
     g = torch.Generator().manual_seed(D + W)
-    y0 = (torch.randn(N, 32, D, H, W, generator=g) * 1.5 + 0.3).to(BF).to(DEV).contiguous(memory_format=CL)
+    y0 = (torch.randn(N, 32, D, H, W, generator=g) * 1.5 + 0.3).to(BF if dt == "bf16" else torch.float32).to(DEV) \
+        .contiguous(memory_format=CL)
     gamma, beta = (torch.rand(32, generator=g) + 0.5).to(DEV), (torch.randn(32, generator=g) * 0.2).to(DEV)
     w = (torch.randn(5, 32, 1, 1, 1, generator=g) * 0.2).to(DEV)
     b = (torch.randn(5, generator=g) * 0.1).to(DEV)
@@ -663,7 +665,7 @@ def test_norm_act_seghead_node_is_bit_identical_to_the_two_separate_nodes(N, D, 
         if fused:
             lg = ops.NormActSegHeadFn.apply(yy, ps[0], ps[1], 1e-5, 0.01, ps[2], ps[3])
         else:
-            lg = ops.SegHeadFn.apply(ops.InstanceNormLeakyReLUFn.apply(yy, ps[0], ps[1], 1e-5, 0.01, True), ps[2], ps[3])
+            lg = ops.SegHeadFn.apply(ops.InstanceNormLeakyReLUFn.apply(yy, ps[0], ps[1], 1e-5, 0.01, dt == "bf16"), ps[2], ps[3])
         lg.backward(gl)
         return [lg.detach(), yy.grad] + [p.grad for p in ps]
     assert ops.fused_norm_seghead_ok(y0, w)
@@ -671,7 +673,8 @@ def test_norm_act_seghead_node_is_bit_identical_to_the_two_separate_nodes(N, D, 
         assert torch.equal(u, v), n
 
 
-def test_train_step_with_the_seg_head_fusion_is_bit_identical_and_it_runs():
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_train_step_with_the_seg_head_fusion_is_bit_identical_and_it_runs(precision):
     from multimodal_mvd_seg_amd import network, trainer
     strides = [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
     plans = trainer.make_plans((64, 64, 64), strides, batch_size=2)
@@ -682,7 +685,7 @@ def test_train_step_with_the_seg_head_fusion_is_bit_identical_and_it_runs():
         for mode in (True, False):
             network.FUSE_SEGHEAD[0] = mode
             tr = trainer.nnUNetTrainerMI355(plans, "3d_fullres", 0, ds, device=DEV)
-            tr.precision = "bf16"
+            tr.precision = precision
             tr.use_hip_graph = False
             torch.manual_seed(0)
             tr.initialize()
@@ -690,7 +693,7 @@ def test_train_step_with_the_seg_head_fusion_is_bit_identical_and_it_runs():
             orig_call = network.ops.call
 
             def counting_call(name, *a, **k):
-                n_fused[0] += name == "mvd_seghead_fwd_bf16_fused"
+                n_fused[0] += name in ("mvd_seghead_fwd_bf16_fused", "mvd_seghead_fwd_fused")
                 return orig_call(name, *a, **k)
             network.ops.call = counting_call
             try:
